@@ -1,0 +1,408 @@
+// extern "C" boundary of libcpt_amd.so (declarations and contracts: include/cpt_amd.h).
+#include "../../include/cpt_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "host/film.hpp"
+#include "host/loader.hpp"
+#include "host/pathtracer.hpp"
+#include "host/scene.hpp"
+#include "lbvh.h"
+#include "render.h"
+
+namespace {
+thread_local std::string g_error;
+
+int Fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+int HipFail(hipError_t e, const char *what) { return Fail(CPT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+
+template <typename F> int Guard(F &&fn) {
+    try {
+        return fn();
+    } catch (const std::exception &e) {
+        return Fail(CPT_ERR_DEVICE, e.what());
+    } catch (...) {
+        return Fail(CPT_ERR_DEVICE, "unknown failure");
+    }
+}
+
+cpt::Bbox MakeBox(const float b[8]) {
+    cpt::Bbox r;
+    memcpy(&r, b, 32);
+    return r;
+}
+}  // namespace
+
+struct cpt_scene {
+    Scene scene;
+};
+
+struct cpt_tracer {
+    cpt_scene *owner;
+    std::unique_ptr<Film> film;
+    std::unique_ptr<PathTracer> tracer;
+};
+
+struct cpt_builder {
+    cpt::BuildWorkspace ws;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+extern "C" {
+
+const char *cpt_last_error(void) { return g_error.c_str(); }
+
+int cpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cpt_set_device(int device) {
+    hipError_t e = hipSetDevice(device);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipSetDevice");
+}
+
+void *cpt_malloc(size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { HipFail(e, "hipMalloc"); return nullptr; }
+    return p;
+}
+int cpt_free(void *d_ptr) {
+    hipError_t e = hipFree(d_ptr);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipFree");
+}
+int cpt_memcpy_h2d(void *d_dst, const void *src, size_t bytes) {
+    hipError_t e = hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemcpy H2D");
+}
+int cpt_memcpy_d2h(void *dst, const void *d_src, size_t bytes) {
+    hipError_t e = hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemcpy D2H");
+}
+int cpt_memset(void *d_dst, int value, size_t bytes) {
+    hipError_t e = hipMemset(d_dst, value, bytes);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemset");
+}
+int cpt_synchronize(void) {
+    hipError_t e = hipDeviceSynchronize();
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipDeviceSynchronize");
+}
+
+// ------------------------------------------------------------------ LBVH
+int cpt_build_accel(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives) {
+    return cpt_build_accel_ex(d_nodes, d_bboxes, merged_bbox, num_primitives, nullptr, nullptr, nullptr);
+}
+
+int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives, uint64_t *d_keys_out,
+                       uint32_t *d_parents_out, float *stage_ms) {
+    if (num_primitives == 0) return CPT_OK;
+    if (!d_nodes || !d_bboxes || !merged_bbox) return Fail(CPT_ERR_INVALID, "cpt_build_accel: null argument");
+    if (num_primitives > 0x7fffffffu) return Fail(CPT_ERR_INVALID, "cpt_build_accel: more than 2^31-1 primitives");
+    int rc = cpt::lbvh_build(static_cast<cpt::AccelNode *>(d_nodes), static_cast<cpt::Bbox *>(d_bboxes), MakeBox(merged_bbox), num_primitives, nullptr,
+                             nullptr, nullptr, d_keys_out, d_parents_out, stage_ms);
+    if (rc != 0) return HipFail((hipError_t)rc, "lbvh_build");
+    hipError_t e = hipDeviceSynchronize();
+    return e == hipSuccess ? CPT_OK : HipFail(e, "lbvh_build");
+}
+
+cpt_builder *cpt_builder_create(void) { return new cpt_builder(); }
+
+void cpt_builder_destroy(cpt_builder *b) {
+    if (!b) return;
+    b->ws.release();
+    if (b->e0) (void)hipEventDestroy(b->e0);
+    if (b->e1) (void)hipEventDestroy(b->e1);
+    delete b;
+}
+
+int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
+                      uint32_t num_primitives, float *elapsed_ms, float *stage_ms) {
+    if (!b || !d_nodes || !d_bboxes || !merged_bbox) return Fail(CPT_ERR_INVALID, "cpt_builder_build: null argument");
+    if (num_primitives == 0) return CPT_OK;
+    if (num_primitives > 0x7fffffffu) return Fail(CPT_ERR_INVALID, "cpt_builder_build: more than 2^31-1 primitives");
+    if (elapsed_ms) {
+        if (!b->e0) { hipError_t e = hipEventCreate(&b->e0); if (e != hipSuccess) return HipFail(e, "hipEventCreate"); }
+        if (!b->e1) { hipError_t e = hipEventCreate(&b->e1); if (e != hipSuccess) return HipFail(e, "hipEventCreate"); }
+        int rc0 = b->ws.reserve(num_primitives);     // keep the allocation out of the timed region
+        if (rc0) return HipFail((hipError_t)rc0, "workspace");
+        (void)hipEventRecord(b->e0, nullptr);
+    }
+    int rc = cpt::lbvh_build(static_cast<cpt::AccelNode *>(d_nodes), static_cast<cpt::Bbox *>(d_bboxes), MakeBox(merged_bbox), num_primitives, nullptr,
+                             &b->ws, static_cast<const cpt::Bbox *>(d_leaf_boxes), nullptr, nullptr, stage_ms);
+    if (rc != 0) return HipFail((hipError_t)rc, "lbvh_build");
+    if (elapsed_ms) {
+        (void)hipEventRecord(b->e1, nullptr);
+        hipError_t e = hipEventSynchronize(b->e1);
+        if (e != hipSuccess) return HipFail(e, "hipEventSynchronize");
+        (void)hipEventElapsedTime(elapsed_ms, b->e0, b->e1);
+    }
+    return CPT_OK;
+}
+
+// ------------------------------------------------------------------ scene
+cpt_scene *cpt_scene_create(void) { return new cpt_scene(); }
+void cpt_scene_destroy(cpt_scene *s) { delete s; }
+
+int cpt_scene_load_obj(cpt_scene *s, const char *path, int bsdf_type) {
+    if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_obj: null argument");
+    return Guard([&] { return LoadObjScene(s->scene, path, bsdf_type) ? CPT_OK : Fail(CPT_ERR_IO, std::string("failed to load obj file '") + path + "'"); });
+}
+int cpt_scene_load_json(cpt_scene *s, const char *path) {
+    if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_json: null argument");
+    return Guard([&] { return LoadJsonScene(s->scene, path) ? CPT_OK : Fail(CPT_ERR_IO, std::string("failed to load json file '") + path + "'"); });
+}
+int cpt_scene_load_xml(cpt_scene *s, const char *path) {
+    if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_xml: null argument");
+    return Guard([&] { return LoadXmlScene(s->scene, path) ? CPT_OK : Fail(CPT_ERR_IO, std::string("failed to load xml file '") + path + "'"); });
+}
+
+int cpt_scene_add_object(cpt_scene *s, const char *name, const float *positions, const float *normals, const float *texcoords,
+                         uint32_t num_vertices, const uint32_t *indices, uint32_t num_triangles, const float material16[16],
+                         const float *transform16) {
+    if (!s || !positions || !normals || !texcoords || !indices || !material16) return Fail(CPT_ERR_INVALID, "cpt_scene_add_object: null argument");
+    for (size_t i = 0; i < 3 * (size_t)num_triangles; i++)
+        if (indices[i] >= num_vertices) return Fail(CPT_ERR_INVALID, "cpt_scene_add_object: vertex index out of range");
+    if (transform16) {
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (memcmp(transform16, ident, sizeof(ident)) != 0)
+            return Fail(CPT_ERR_INVALID, "cpt_scene_add_object: only identity transforms can be given here; set translate/rotate/scale on the object");
+    }
+    return Guard([&] {
+        auto object = s->scene.AddObject(name ? name : "");
+        auto mesh = std::make_shared<Mesh>();
+        std::vector<cpt::V3> pos(num_vertices), nrm(num_vertices);
+        std::vector<cpt::V2> uv(num_vertices);
+        memcpy(pos.data(), positions, 12 * (size_t)num_vertices);
+        memcpy(nrm.data(), normals, 12 * (size_t)num_vertices);
+        memcpy(uv.data(), texcoords, 8 * (size_t)num_vertices);
+        mesh->SetPositions(std::move(pos));
+        mesh->SetNormals(std::move(nrm));
+        mesh->SetTexcoords(std::move(uv));
+        mesh->SetIndices(std::vector<uint32_t>(indices, indices + 3 * (size_t)num_triangles));
+        object->AddComponent<MeshComponent>()->SetMesh(mesh);
+        auto mat = std::make_shared<Material>();
+        mat->name = name ? name : "";
+        mat->emission = cpt::V3{material16[0], material16[1], material16[2]};
+        mat->diffuse = cpt::V3{material16[3], material16[4], material16[5]};
+        mat->specular = cpt::V3{material16[6], material16[7], material16[8]};
+        mat->transmittance = cpt::V3{material16[9], material16[10], material16[11]};
+        mat->shininess = material16[12];
+        mat->ior = material16[13];
+        mat->opacity = material16[14];
+        mat->bsdf_type = (int)material16[15];
+        mat->SetChanged();
+        object->AddComponent<MaterialComponent>()->SetMaterial(mat);
+        return CPT_OK;
+    });
+}
+
+int cpt_scene_set_camera(cpt_scene *s, const float pos[3], const float look_at[3], const float up[3], float fov_degrees, uint32_t film_width,
+                         uint32_t film_height) {
+    if (!s || !pos || !look_at || !up) return Fail(CPT_ERR_INVALID, "cpt_scene_set_camera: null argument");
+    auto existing = s->scene.FirstObjectWith<CameraComponent>();
+    auto object = existing ? existing : s->scene.AddObject("camera");
+    CameraComponent *c = existing ? object->GetComponent<CameraComponent>() : object->AddComponent<CameraComponent>();
+    c->pos = cpt::V3{pos[0], pos[1], pos[2]};
+    c->look_at = cpt::V3{look_at[0], look_at[1], look_at[2]};
+    c->up = cpt::V3{up[0], up[1], up[2]};
+    c->fov = fov_degrees;
+    c->film_width = film_width;
+    c->film_height = film_height;
+    return CPT_OK;
+}
+
+static SceneObject *MeshObject(const cpt_scene *s, uint32_t index) {
+    uint32_t k = 0;
+    for (auto &obj : s->scene.Objects())
+        if (obj->HasComponent<MeshComponent>() && obj->HasComponent<MaterialComponent>()) {
+            if (k == index) return obj.get();
+            k++;
+        }
+    return nullptr;
+}
+
+uint32_t cpt_scene_num_objects(const cpt_scene *s) {
+    if (!s) return 0;
+    uint32_t k = 0;
+    for (auto &obj : s->scene.Objects()) k += (obj->HasComponent<MeshComponent>() && obj->HasComponent<MaterialComponent>()) ? 1 : 0;
+    return k;
+}
+
+int cpt_scene_object_info(const cpt_scene *s, uint32_t index, char *name_buf, size_t name_buf_size, uint32_t *num_vertices, uint32_t *num_triangles,
+                          float material16[16], float transform16[16]) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_info: no such object");
+    const Mesh *mesh = obj->GetComponent<MeshComponent>()->GetMesh();
+    const Material *mat = obj->GetComponent<MaterialComponent>()->GetMaterial();
+    if (name_buf && name_buf_size) {
+        strncpy(name_buf, obj->Name().c_str(), name_buf_size - 1);
+        name_buf[name_buf_size - 1] = '\0';
+    }
+    if (num_vertices) *num_vertices = (uint32_t)mesh->VericesCount();
+    if (num_triangles) *num_triangles = (uint32_t)(mesh->IndicesCount() / 3);
+    if (material16) {
+        const float m[16] = {mat->emission.x, mat->emission.y, mat->emission.z, mat->diffuse.x, mat->diffuse.y, mat->diffuse.z,
+                             mat->specular.x, mat->specular.y, mat->specular.z, mat->transmittance.x, mat->transmittance.y, mat->transmittance.z,
+                             mat->shininess, mat->ior, mat->opacity, (float)mat->bsdf_type};
+        memcpy(material16, m, sizeof(m));
+    }
+    if (transform16) {
+        cpt::M4 t = obj->GetTransform();
+        memcpy(transform16, &t, 64);
+    }
+    return CPT_OK;
+}
+
+int cpt_scene_object_copy(const cpt_scene *s, uint32_t index, float *positions, float *normals, float *texcoords, uint32_t *indices) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_copy: no such object");
+    const Mesh *mesh = obj->GetComponent<MeshComponent>()->GetMesh();
+    if (positions) memcpy(positions, mesh->Positions().data(), 12 * mesh->Positions().size());
+    if (normals) memcpy(normals, mesh->Normals().data(), 12 * mesh->Normals().size());
+    if (texcoords) memcpy(texcoords, mesh->Texcoords().data(), 8 * mesh->Texcoords().size());
+    if (indices) memcpy(indices, mesh->Indices().data(), 4 * mesh->Indices().size());
+    return CPT_OK;
+}
+
+int cpt_scene_camera(const cpt_scene *s, float cam10[10], uint32_t res2[2]) {
+    if (!s) return Fail(CPT_ERR_INVALID, "cpt_scene_camera: null scene");
+    auto obj = s->scene.FirstObjectWith<CameraComponent>();
+    if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_camera: the scene has no camera");
+    const CameraComponent *c = obj->GetComponent<CameraComponent>();
+    if (cam10) {
+        const float v[10] = {c->pos.x, c->pos.y, c->pos.z, c->look_at.x, c->look_at.y, c->look_at.z, c->up.x, c->up.y, c->up.z, c->fov};
+        memcpy(cam10, v, sizeof(v));
+    }
+    if (res2) { res2[0] = c->film_width; res2[1] = c->film_height; }
+    return CPT_OK;
+}
+
+// ------------------------------------------------------------------ tracer
+cpt_tracer *cpt_tracer_create(cpt_scene *s, uint32_t film_width, uint32_t film_height) {
+    if (!s || film_width == 0 || film_height == 0) { Fail(CPT_ERR_INVALID, "cpt_tracer_create: bad argument"); return nullptr; }
+    auto *t = new cpt_tracer();
+    t->owner = s;
+    t->film = std::make_unique<Film>(film_width, film_height);
+    t->tracer = std::make_unique<PathTracer>(s->scene, *t->film);
+    return t;
+}
+void cpt_tracer_destroy(cpt_tracer *t) { delete t; }
+
+#define TRACER_OR_FAIL(t) do { if (!(t)) return Fail(CPT_ERR_INVALID, "null tracer"); } while (0)
+
+int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth) { TRACER_OR_FAIL(t); t->tracer->SetMaxDepth(max_depth); return CPT_OK; }
+int cpt_tracer_set_channel(cpt_tracer *t, int channel) { TRACER_OR_FAIL(t); t->tracer->SetChannel(channel); return CPT_OK; }
+int cpt_tracer_set_profile_build(cpt_tracer *t, int on) { TRACER_OR_FAIL(t); t->tracer->SetProfileBuild(on != 0); return CPT_OK; }
+int cpt_tracer_build_buffers(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->BuildBuffers(); return CPT_OK; });
+}
+int cpt_tracer_update(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->Update(); return CPT_OK; });
+}
+int cpt_tracer_reset_accumulation(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->ResetAccumelation(); t->film->Clear(t->tracer->Stream()); return CPT_OK; });
+}
+int cpt_tracer_synchronize(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->Synchronize(); return CPT_OK; });
+}
+uint32_t cpt_tracer_current_spp(const cpt_tracer *t) { return t ? t->tracer->CurrentSpp() : 0; }
+uint32_t cpt_tracer_num_lights(const cpt_tracer *t) { return t ? t->tracer->NumLights() : 0; }
+
+int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_count, int sum_mode, float *d_output, uint32_t width, uint32_t height) {
+    TRACER_OR_FAIL(t);
+    if (spp_begin == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_render_samples: sample indices are 1-based");
+    if (d_output && (width == 0 || height == 0)) return Fail(CPT_ERR_INVALID, "cpt_tracer_render_samples: zero-sized output");
+    return Guard([&] { t->tracer->RenderSamples(spp_begin, spp_count, sum_mode != 0, d_output, width, height); return CPT_OK; });
+}
+
+float *cpt_tracer_film_device_ptr(cpt_tracer *t) {
+    if (!t) return nullptr;
+    try { return t->film->DeviceMap(); } catch (const std::exception &e) { Fail(CPT_ERR_DEVICE, e.what()); return nullptr; }
+}
+int cpt_tracer_film_read(cpt_tracer *t, float *rgba) {
+    TRACER_OR_FAIL(t);
+    if (!rgba) return Fail(CPT_ERR_INVALID, "cpt_tracer_film_read: null buffer");
+    return Guard([&] { t->tracer->Synchronize(); t->film->ReadBack(rgba); return CPT_OK; });
+}
+int cpt_tracer_film_save(cpt_tracer *t, const char *path) {
+    TRACER_OR_FAIL(t);
+    if (!path) return Fail(CPT_ERR_INVALID, "cpt_tracer_film_save: null path");
+    return Guard([&] { t->tracer->Synchronize(); return t->film->SaveTo(path) ? CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'"); });
+}
+
+int cpt_tracer_first_hit(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint32_t *d_instance, uint32_t *d_primitive, float *d_t, float *d_uv) {
+    TRACER_OR_FAIL(t);
+    if (num_rays == 0) return CPT_OK;
+    if (!d_rays || !d_instance || !d_primitive) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: null argument");
+    if (t->tracer->NumInstances() == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: build_buffers has not produced any geometry");
+    int rc = cpt::launch_first_hit(t->tracer->DeviceScene(), d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, t->tracer->Stream());
+    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "first_hit");
+}
+int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint8_t *d_occluded) {
+    TRACER_OR_FAIL(t);
+    if (num_rays == 0) return CPT_OK;
+    if (!d_rays || !d_occluded) return Fail(CPT_ERR_INVALID, "cpt_tracer_occlude: null argument");
+    if (t->tracer->NumInstances() == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_occlude: build_buffers has not produced any geometry");
+    int rc = cpt::launch_occlude(t->tracer->DeviceScene(), d_rays, num_rays, d_occluded, t->tracer->Stream());
+    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "occlude");
+}
+int cpt_tracer_camera_rays(cpt_tracer *t, uint32_t width, uint32_t height, uint32_t spp, float *d_rays) {
+    TRACER_OR_FAIL(t);
+    if (!d_rays || spp == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_camera_rays: bad argument");
+    int rc = cpt::launch_camera_rays(t->tracer->DeviceScene().camera, width, height, spp, d_rays, t->tracer->Stream());
+    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "camera_rays");
+}
+
+int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bboxes, uint64_t *keys) {
+    if (!t) return Fail(CPT_ERR_INVALID, "null tracer");
+    PathTracer::AccelView v = t->tracer->Accel(mesh);
+    if (!v.nodes) return Fail(CPT_ERR_INVALID, "cpt_tracer_get_accel: no such structure");
+    int rc = Guard([&] {
+        t->tracer->Synchronize();
+        size_t nn = 2 * (size_t)v.num_primitives - 1;
+        if (nodes) CPT_HIP(hipMemcpy(nodes, v.nodes, 8 * nn, hipMemcpyDeviceToHost));
+        if (bboxes) CPT_HIP(hipMemcpy(bboxes, v.bboxes, 32 * nn, hipMemcpyDeviceToHost));
+        if (keys) CPT_HIP(hipMemcpy(keys, v.keys, 8 * (size_t)v.num_primitives, hipMemcpyDeviceToHost));
+        return CPT_OK;
+    });
+    return rc == CPT_OK ? (int64_t)v.num_primitives : rc;
+}
+
+int cpt_tracer_counters(cpt_tracer *t, uint64_t out4[4]) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] {
+        unsigned long long c[4];
+        t->tracer->ReadCounters(c);
+        for (int i = 0; i < 4; i++) out4[i] = c[i];
+        return CPT_OK;
+    });
+}
+int cpt_tracer_reset_counters(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->ResetCounters(); return CPT_OK; });
+}
+int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]) {
+    TRACER_OR_FAIL(t);
+    memcpy(out5, t->tracer->BuildStageMs(), 5 * sizeof(float));
+    return CPT_OK;
+}
+
+int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height) {
+    if (!path || !rgba) return Fail(CPT_ERR_INVALID, "cpt_write_exr: null argument");
+    return WriteExrRgba(path, rgba, width, height) ? CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'");
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Data layout in HBM for the three device subsystems (LBVH build, traversal, bounce loop).
+#pragma once
+#include "vecmath.h"
+
+namespace cpt {
+
+// ---- build-side layout: identical to the reference's arrays so kernel::BuildAccel callers can
+// be pointed at the same buffers (src/kernels/accel/accel.cuh:15-23).
+struct Bbox { V4 pmin, pmax; };                 // 32 B; w = 1 on leaves
+struct AccelNode { uint32_t lc_or_id, rc; };    // 8 B; leaf <=> rc == ~0u, then lc_or_id = original primitive index
+static_assert(sizeof(Bbox) == 32 && sizeof(AccelNode) == 8, "reference layout");
+
+// ---- traversal-side layout.
+// One 64-byte record per internal node holding BOTH children's boxes and references, fetched
+// with four 16-byte loads from one half cache line.  A child reference with bit 31 set is a
+// leaf: its low bits are a triangle-record slot (bottom level) or an instance id (top level).
+struct alignas(64) PackedNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t lc, rc;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PackedNode) == 64, "one record per 64 B");
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+// 48-byte triangle record in sorted-leaf order: p0, e1 = p1 - p0, e2 = p2 - p0 (single fp32
+// subtractions, so the values equal what src/kernels/geometry/trimesh.cuh:21-22 computes per
+// test) plus the original primitive index.
+struct alignas(16) TriRecord {
+    float p0[3]; uint32_t prim;
+    float e1[3]; uint32_t pad0;
+    float e2[3]; uint32_t pad1;
+};
+static_assert(sizeof(TriRecord) == 48, "three 16 B loads");
+
+// Root of one packed BVH: the root's own box is tested once, as the reference does when it
+// pops node 0 (accel.cuh:73-75); ref is a leaf reference when the BVH has a single primitive.
+struct AccelRoot {
+    float bmin[3], bmax[3];
+    uint32_t ref;
+    uint32_t num_prims;
+};
+
+struct MeshDev {
+    const PackedNode *nodes;
+    const TriRecord *tris;
+    const uint32_t *indices;
+    const V3 *positions;
+    const V3 *normals;
+    const V2 *texcoords;
+    AccelRoot root;
+    uint32_t num_triangles;
+    uint32_t pad;
+};
+
+struct InstanceDev {
+    M4 transform;        // object -> world
+    M4 transform_inv;    // world -> object
+    M4 transform_it;     // transpose(transform_inv)
+    uint32_t mesh;
+    uint32_t material;
+    int32_t light;       // index into the light table or -1
+    uint32_t pad;
+};
+
+enum BsdfType : int { kLambert = 0, kPhong = 1, kBlinnPhong = 2, kMicrofacet = 3, kGlass = 4 };   // src/kernels/bsdf/bsdf.cuh:14-20
+enum LobeType : int { kLobeNone = 0, kLobeDiffuse = 1, kLobeGlossy = 2, kLobeSpecular = 3 };      // src/kernels/bsdf/common.cuh:8-13
+
+// BSDF parameter block per material, evaluated once on the host from the MTL values
+// (src/kernels/material/mtl.cuh:16-66 has no uv dependence without textures).
+// Glass keeps reflectance in `diffuse` and transmittance in `specular`.
+struct BsdfDev {
+    int type;
+    V3 emission;
+    V3 diffuse;
+    V3 specular;
+    V3 transmittance;
+    float shininess, s_norm, ior, roughness, opacity;
+    float pad[2];
+};
+static_assert(sizeof(BsdfDev) == 80, "five 16 B loads");
+
+struct CameraDev { V3 pos, frame_x, frame_y, frame_z, x_dir, y_dir; };   // src/kernels/camera/pinhole.cuh:8-14
+
+struct Counters {
+    unsigned long long rays;        // closest-hit + any-hit queries
+    unsigned long long node_visits; // 64-byte records fetched
+    unsigned long long tri_tests;   // triangle records fetched
+    unsigned long long paths;       // camera paths started
+};
+
+struct SceneDev {
+    const PackedNode *top_nodes;
+    const AccelRoot *top_root;
+    const InstanceDev *instances;
+    const MeshDev *meshes;
+    const BsdfDev *materials;
+    const uint32_t *lights;     // instance index of each light
+    uint32_t num_lights;
+    float light_pick_pdf;
+    CameraDev camera;
+    Counters *counters;         // may be null
+};
+
+struct RenderParams {
+    float *output;              // W*H float4, row 0 = top of the image
+    uint32_t width, height;
+    uint32_t spp;               // 1-based sample index of this pass
+    uint32_t max_depth;         // 0xffffffff = unbounded
+    int channel;                // 0 colour, 1 normal
+    int sum_mode;               // 0: running mean (reference semantics); 1: plain sum (sharded renders)
+};
+
+}  // namespace cpt

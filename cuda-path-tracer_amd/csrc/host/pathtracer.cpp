@@ -1,0 +1,297 @@
+#include "pathtracer.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "../render.h"
+#include "../shading.h"
+
+using cpt::M4;
+using cpt::V3;
+using cpt::V4;
+
+namespace {
+
+// general 4x4 inverse by cofactors in double; every scene produced by the loaders has identity
+// transforms, for which this returns the identity exactly
+M4 Inverse(const M4 &mm) {
+    const float *m = &mm.c[0].x;
+    double a[16], inv[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
+    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
+    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
+    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
+    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
+    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
+    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
+    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
+    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
+    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
+    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
+    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
+    double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+    M4 r;
+    float *o = &r.c[0].x;
+    for (int i = 0; i < 16; i++) {
+        double v = inv[i] / det;
+        o[i] = (v == 0.0) ? 0.0f : (float)v;
+    }
+    return r;
+}
+
+inline void rc_check(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
+}
+
+}  // namespace
+
+PathTracer::PathTracer(Scene &scene, Film &film) : scene_(scene), film_(film) {}
+
+PathTracer::~PathTracer() {
+    workspace_.release();
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void PathTracer::BuildBuffers() {
+    if (!stream_) CPT_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    BuildAccel();
+
+    // src/scene/camera.cpp:28-50
+    has_camera_ = false;
+    scene_.ForEach<CameraComponent>([this](CameraComponent &camera) {
+        V3 frame_z = cpt::normalize(camera.pos - camera.look_at);
+        V3 frame_x = cpt::normalize(cpt::cross(camera.up, frame_z));
+        V3 frame_y = cpt::normalize(cpt::cross(frame_z, frame_x));
+        float radians = (camera.fov * 0.5f) * 0.01745329251994329576923690768489f;
+        float scale = std::tan(radians) * 2.0f;
+        scene_dev_.camera = cpt::CameraDev{camera.pos, frame_x, frame_y, frame_z, V3{scale, 0.0f, 0.0f}, V3{0.0f, scale, 0.0f}};
+        has_camera_ = true;
+    });
+
+    BuildInstancesAndLights();
+    CPT_HIP(hipStreamSynchronize(stream_));
+    built_ = true;
+}
+
+// src/pathtracer/pathtracer.cpp:91-166 and src/scene/mesh.cpp:84-149
+void PathTracer::BuildAccel() {
+    meshes_.clear();
+    mesh_index_.clear();
+    instance_mesh_.clear();
+    memset(build_stage_ms_, 0, sizeof(build_stage_ms_));
+    uint32_t largest = 0;
+
+    std::vector<cpt::Bbox> leaf_bboxes;
+    scene_.ForEach<MeshComponent, const MaterialComponent>([&](SceneObject &object, MeshComponent &mesh_comp, const MaterialComponent &) {
+        Mesh *mesh = mesh_comp.GetMesh();
+        uint32_t n = (uint32_t)(mesh->IndicesCount() / 3);
+        if (n == 0) return;
+        if (mesh->Normals().size() != mesh->VericesCount() || mesh->Texcoords().size() != mesh->VericesCount())
+            throw std::runtime_error("mesh '" + object.Name() + "' lacks per-vertex normals or texture coordinates");
+        auto found = mesh_index_.find(mesh);
+        if (found == mesh_index_.end()) {
+            auto mb = std::make_unique<MeshBuffers>();
+            mb->num_triangles = n;
+            mb->positions.Allocate(sizeof(V3) * mesh->VericesCount(), mesh->Positions().data(), stream_);
+            mb->normals.Allocate(sizeof(V3) * mesh->VericesCount(), mesh->Normals().data(), stream_);
+            mb->texcoords.Allocate(sizeof(cpt::V2) * mesh->VericesCount(), mesh->Texcoords().data(), stream_);
+            mb->indices.Allocate(sizeof(uint32_t) * mesh->IndicesCount(), mesh->Indices().data(), stream_);
+            size_t num_nodes = 2 * (size_t)n - 1;
+            mb->nodes.Allocate(sizeof(cpt::AccelNode) * num_nodes);
+            mb->bboxes.Allocate(sizeof(cpt::Bbox) * num_nodes);
+            mb->keys.Allocate(sizeof(uint64_t) * n);
+            mb->packed_nodes.Allocate(sizeof(cpt::PackedNode) * (n > 1 ? n - 1 : 1));
+            mb->tris.Allocate(sizeof(cpt::TriRecord) * n);
+            leaf_scratch_.Allocate(sizeof(cpt::Bbox) * (size_t)n);
+
+            // leaf boxes on the device (the reference loops over triangles on the host, mesh.cpp:88-98)
+            rc_check(cpt::lbvh_triangle_boxes(leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->indices.TypedGpuData<uint32_t>(),
+                                              mb->positions.TypedGpuData<V3>(), n, stream_), "triangle boxes");
+            const struct Bbox &hb = mesh->Bbox();
+            cpt::Bbox merged{V4{hb.pmin.x, hb.pmin.y, hb.pmin.z, 1.0f}, V4{hb.pmax.x, hb.pmax.y, hb.pmax.z, 1.0f}};
+            bool profile = profile_build_ && n >= largest;
+            float stage[5];
+            rc_check(cpt::lbvh_build(mb->nodes.TypedGpuData<cpt::AccelNode>(), mb->bboxes.TypedGpuData<cpt::Bbox>(), merged, n, stream_, &workspace_,
+                                     leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->keys.TypedGpuData<uint64_t>(), nullptr, profile ? stage : nullptr),
+                     "bottom-level build");
+            if (profile) { memcpy(build_stage_ms_, stage, sizeof(stage)); largest = n; }
+            found = mesh_index_.emplace(mesh, (uint32_t)meshes_.size()).first;
+            meshes_.push_back(std::move(mb));
+        }
+        instance_mesh_.push_back(found->second);
+
+        // top-level leaf = mesh bounds carried through the object's transform (pathtracer.cpp:103-109)
+        struct Bbox bbox = mesh->Bbox().TransformBy(object.GetTransform());
+        leaf_bboxes.push_back(cpt::Bbox{V4{bbox.pmin.x, bbox.pmin.y, bbox.pmin.z, 1.0f}, V4{bbox.pmax.x, bbox.pmax.y, bbox.pmax.z, 1.0f}});
+    });
+
+    uint32_t num_instances = (uint32_t)instance_mesh_.size();
+    if (num_instances == 0) return;
+
+    // mesh descriptor table; the pack kernels fill in each root afterwards
+    std::vector<cpt::MeshDev> mesh_table(meshes_.size());
+    for (size_t i = 0; i < meshes_.size(); i++) {
+        MeshBuffers &mb = *meshes_[i];
+        cpt::MeshDev &d = mesh_table[i];
+        memset(&d, 0, sizeof(d));
+        d.nodes = mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
+        d.tris = mb.tris.TypedGpuData<cpt::TriRecord>();
+        d.indices = mb.indices.TypedGpuData<uint32_t>();
+        d.positions = mb.positions.TypedGpuData<V3>();
+        d.normals = mb.normals.TypedGpuData<V3>();
+        d.texcoords = mb.texcoords.TypedGpuData<cpt::V2>();
+        d.num_triangles = mb.num_triangles;
+    }
+    mesh_table_.Allocate(sizeof(cpt::MeshDev) * mesh_table.size(), mesh_table.data(), stream_);
+    for (size_t i = 0; i < meshes_.size(); i++) {
+        MeshBuffers &mb = *meshes_[i];
+        cpt::AccelRoot *root = &mesh_table_.TypedGpuData<cpt::MeshDev>()[i].root;
+        rc_check(cpt::lbvh_pack(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.tris.TypedGpuData<cpt::TriRecord>(), root,
+                                mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles,
+                                mb.indices.TypedGpuData<uint32_t>(), mb.positions.TypedGpuData<V3>(), stream_), "pack bottom level");
+    }
+
+    // top level (pathtracer.cpp:120-154)
+    size_t num_nodes = 2 * (size_t)num_instances - 1;
+    std::vector<cpt::Bbox> accel_bboxes(num_nodes);
+    memset(accel_bboxes.data(), 0, sizeof(cpt::Bbox) * num_nodes);
+    std::copy(leaf_bboxes.begin(), leaf_bboxes.end(), accel_bboxes.begin() + (num_instances - 1));
+    const float fmax_ = 3.402823466e+38f;
+    cpt::Bbox merged{V4{fmax_, fmax_, fmax_, 1.0f}, V4{-fmax_, -fmax_, -fmax_, 1.0f}};
+    for (uint32_t i = 0; i < num_instances; i++) {
+        const cpt::Bbox &b = accel_bboxes[num_instances - 1 + i];
+        merged.pmin = V4{cpt::gmin(merged.pmin.x, b.pmin.x), cpt::gmin(merged.pmin.y, b.pmin.y), cpt::gmin(merged.pmin.z, b.pmin.z), cpt::gmin(merged.pmin.w, b.pmin.w)};
+        merged.pmax = V4{cpt::gmax(merged.pmax.x, b.pmax.x), cpt::gmax(merged.pmax.y, b.pmax.y), cpt::gmax(merged.pmax.z, b.pmax.z), cpt::gmax(merged.pmax.w, b.pmax.w)};
+    }
+    top_bboxes_.Allocate(sizeof(cpt::Bbox) * num_nodes, accel_bboxes.data(), stream_);
+    top_nodes_.Allocate(sizeof(cpt::AccelNode) * num_nodes);
+    top_keys_.Allocate(sizeof(uint64_t) * num_instances);
+    top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
+    top_root_.Allocate(sizeof(cpt::AccelRoot));
+    rc_check(cpt::lbvh_build(top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), merged, num_instances, stream_, &workspace_,
+                             nullptr, top_keys_.TypedGpuData<uint64_t>(), nullptr, nullptr), "top-level build");
+    rc_check(cpt::lbvh_pack(top_packed_.TypedGpuData<cpt::PackedNode>(), nullptr, top_root_.TypedGpuData<cpt::AccelRoot>(),
+                            top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), num_instances, nullptr, nullptr, stream_),
+             "pack top level");
+
+    scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
+    scene_dev_.top_root = top_root_.TypedGpuData<cpt::AccelRoot>();
+    scene_dev_.meshes = mesh_table_.TypedGpuData<cpt::MeshDev>();
+}
+
+// src/pathtracer/pathtracer.cpp:168-221
+void PathTracer::BuildInstancesAndLights() {
+    std::vector<cpt::InstanceDev> instances;
+    std::vector<cpt::BsdfDev> materials;
+    std::vector<uint32_t> lights;
+    std::unordered_map<const Material *, uint32_t> material_index;
+    uint32_t slot = 0;
+
+    scene_.ForEach<const MeshComponent, const MaterialComponent>([&](SceneObject &object, const MeshComponent &mesh, const MaterialComponent &material) {
+        if (mesh.GetMesh()->IndicesCount() / 3 == 0) return;
+        const Material *mat = material.GetMaterial();
+        auto found = material_index.find(mat);
+        if (found == material_index.end()) {
+            found = material_index.emplace(mat, (uint32_t)materials.size()).first;
+            materials.push_back(cpt::make_bsdf(mat->emission, mat->diffuse, mat->specular, mat->transmittance, mat->shininess, mat->ior, mat->opacity,
+                                               mat->bsdf_type));
+        }
+        cpt::InstanceDev inst;
+        memset(&inst, 0, sizeof(inst));
+        inst.transform = object.GetTransform();
+        inst.transform_inv = Inverse(inst.transform);
+        inst.transform_it = cpt::transpose(inst.transform_inv);
+        inst.mesh = instance_mesh_[slot];
+        inst.material = found->second;
+        inst.light = -1;
+        if (mat->IsEmissive()) {
+            inst.light = (int32_t)lights.size();
+            lights.push_back(slot);
+        }
+        instances.push_back(inst);
+        slot++;
+    });
+
+    num_lights_ = (uint32_t)lights.size();
+    if (!instances.empty()) instance_table_.Allocate(sizeof(cpt::InstanceDev) * instances.size(), instances.data(), stream_);
+    if (!materials.empty()) material_table_.Allocate(sizeof(cpt::BsdfDev) * materials.size(), materials.data(), stream_);
+    if (!lights.empty()) light_table_.Allocate(sizeof(uint32_t) * lights.size(), lights.data(), stream_);
+    counters_.Allocate(sizeof(cpt::Counters));
+    counters_.Zero(stream_);
+
+    scene_dev_.instances = instance_table_.TypedGpuData<cpt::InstanceDev>();
+    scene_dev_.materials = material_table_.TypedGpuData<cpt::BsdfDev>();
+    scene_dev_.lights = light_table_.TypedGpuData<uint32_t>();
+    scene_dev_.num_lights = num_lights_;
+    scene_dev_.light_pick_pdf = num_lights_ != 0 ? 1.0f / num_lights_ : 0.0f;    // pathtracer.cpp:47
+    scene_dev_.counters = counters_.TypedGpuData<cpt::Counters>();
+}
+
+void PathTracer::ResetAccumelation() { curr_spp_ = 0; }
+
+// src/pathtracer/pathtracer.cpp:26-61
+void PathTracer::Update() {
+    if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
+    if (film_.Width() != last_width_ || film_.Height() != last_height_) {
+        ResetAccumelation();
+        last_width_ = film_.Width();
+        last_height_ = film_.Height();
+    }
+    ++curr_spp_;
+    cpt::RenderParams p;
+    p.output = film_.DeviceMap();
+    p.width = film_.Width();
+    p.height = film_.Height();
+    p.spp = curr_spp_;
+    p.max_depth = static_cast<uint32_t>(max_depth_);
+    p.channel = display_channel_;
+    p.sum_mode = 0;
+    rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
+    film_.DeviceUnmap();
+}
+
+void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
+    if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
+    cpt::RenderParams p;
+    p.output = output ? output : film_.DeviceMap();
+    p.width = output ? width : film_.Width();
+    p.height = output ? height : film_.Height();
+    p.max_depth = static_cast<uint32_t>(max_depth_);
+    p.channel = display_channel_;
+    p.sum_mode = sum_mode ? 1 : 0;
+    for (uint32_t s = 0; s < count; s++) {
+        p.spp = spp_begin + s;
+        rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
+    }
+}
+
+void PathTracer::Synchronize() {
+    if (stream_) CPT_HIP(hipStreamSynchronize(stream_));
+}
+
+void PathTracer::ReadCounters(unsigned long long out[4]) {
+    cpt::Counters c{};
+    if (counters_.Size()) {
+        CPT_HIP(hipMemcpyAsync(&c, counters_.GpuData(), sizeof(c), hipMemcpyDeviceToHost, stream_));
+        CPT_HIP(hipStreamSynchronize(stream_));
+    }
+    out[0] = c.rays; out[1] = c.node_visits; out[2] = c.tri_tests; out[3] = c.paths;
+}
+
+void PathTracer::ResetCounters() {
+    if (counters_.Size()) counters_.Zero(stream_);
+}
+
+PathTracer::AccelView PathTracer::Accel(int mesh) const {
+    if (mesh < 0)
+        return AccelView{top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), top_keys_.TypedGpuData<uint64_t>(),
+                         (uint32_t)instance_mesh_.size()};
+    if ((size_t)mesh >= instance_mesh_.size()) return AccelView{nullptr, nullptr, nullptr, 0};
+    const MeshBuffers &mb = *meshes_[instance_mesh_[mesh]];
+    return AccelView{mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.keys.TypedGpuData<uint64_t>(), mb.num_triangles};
+}

@@ -1,0 +1,85 @@
+// Host side of the renderer: the reference's PathTracer component
+// (src/pathtracer/pathtracer.hpp:7-50) on the HIP runtime.  BuildBuffers turns the host scene
+// into device tables (per-mesh bottom-level BVH, top-level BVH over instances, instance / material
+// / light tables, camera); Update renders one more sample per pixel into the Film.
+#pragma once
+#include <memory>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../device_types.h"
+#include "../lbvh.h"
+#include "buffer.hpp"
+#include "film.hpp"
+#include "scene.hpp"
+
+class PathTracer {
+public:
+    PathTracer(Scene &scene, Film &film);
+    ~PathTracer();
+
+    void BuildBuffers();
+    void ResetAccumelation();        // [sic] the reference's spelling
+    void Update();
+    void ShowUi() {}                 // the interactive panel is out of scope
+    void SetCaptureName(std::string_view capture_name) { capture_name_ = capture_name; }
+    void SetMaxDepth(int max_depth) { max_depth_ = max_depth; }
+
+    // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
+    void SetChannel(int channel) { display_channel_ = channel; }
+    void Synchronize();
+    uint32_t CurrentSpp() const { return curr_spp_; }
+    uint32_t NumLights() const { return num_lights_; }
+    uint32_t NumInstances() const { return (uint32_t)instance_mesh_.size(); }
+    hipStream_t Stream() const { return stream_; }
+    const cpt::SceneDev &DeviceScene() const { return scene_dev_; }
+    // Renders sample indices [spp_begin, spp_begin + count) (1-based) into `output` (device,
+    // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
+    void RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height);
+    void ReadCounters(unsigned long long out[4]);
+    void ResetCounters();
+
+    struct AccelView { const cpt::AccelNode *nodes; const cpt::Bbox *bboxes; const uint64_t *keys; uint32_t num_primitives; };
+    // mesh < 0: the top-level structure; otherwise the bottom-level structure of instance `mesh`
+    AccelView Accel(int mesh) const;
+    // per-stage milliseconds of the largest bottom-level build of the last BuildBuffers
+    // (morton, sort, gather, karras, refit), valid after SetProfileBuild(true)
+    void SetProfileBuild(bool on) { profile_build_ = on; }
+    const float *BuildStageMs() const { return build_stage_ms_; }
+
+private:
+    void BuildAccel();
+    void BuildInstancesAndLights();
+
+    struct MeshBuffers {
+        cpt::HipBuffer positions, normals, texcoords, indices;
+        cpt::HipBuffer nodes, bboxes, keys;          // reference-layout build output
+        cpt::HipBuffer packed_nodes, tris;           // traversal records
+        uint32_t num_triangles = 0;
+    };
+
+    Scene &scene_;
+    Film &film_;
+    hipStream_t stream_ = nullptr;
+
+    std::string capture_name_;
+    int max_depth_ = -1;
+    uint32_t curr_spp_ = 0;
+    int display_channel_ = 0;
+    uint32_t last_width_ = 0, last_height_ = 0;
+    bool built_ = false, has_camera_ = false;
+    bool profile_build_ = false;
+    float build_stage_ms_[5] = {0, 0, 0, 0, 0};
+
+    cpt::BuildWorkspace workspace_;
+    std::vector<std::unique_ptr<MeshBuffers>> meshes_;
+    std::unordered_map<const Mesh *, uint32_t> mesh_index_;
+    std::vector<uint32_t> instance_mesh_;            // instance -> mesh table index
+    cpt::HipBuffer leaf_scratch_;
+    cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_;
+    cpt::HipBuffer mesh_table_, instance_table_, material_table_, light_table_, counters_;
+    uint32_t num_lights_ = 0;
+    cpt::SceneDev scene_dev_{};
+};

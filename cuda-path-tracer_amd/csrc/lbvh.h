@@ -1,0 +1,41 @@
+// Host entry points of the gfx950 LBVH builder (lbvh.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace cpt {
+
+// Scratch memory of one build, reusable across builds (grown on demand, never shrunk).
+struct BuildWorkspace {
+    void *base = nullptr;
+    size_t capacity = 0;
+    static size_t bytes_for(uint32_t num_primitives);
+    int reserve(uint32_t num_primitives);
+    void release();
+};
+
+// Drop-in for kernel::BuildAccel (src/kernels/accel/accel_build.cuh:7): `nodes` and `bboxes` are
+// device arrays of 2n-1 entries; the leaf boxes occupy bboxes[n-1 .. 2n-2] on entry and are
+// reordered in place; every node and every internal box is written.
+//   ws          optional reusable scratch; when null, scratch is allocated and freed inside and
+//               the call returns only after the build has finished (the reference's behaviour)
+//   leaf_src    optional device array of the n unsorted leaf boxes living OUTSIDE `bboxes`;
+//               when given, bboxes[n-1..] need not be filled and one device copy is saved
+//   keys_out    optional device array of n sorted 64-bit keys (code << 32 | primitive)
+//   parents_out optional device array of 2n-1 parent indices (entry 0 is never written)
+//   stage_ms    optional host array of 5 floats: morton, sort, gather, karras, refit (forces a sync)
+// Returns 0 or a hipError_t value.
+int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t num_primitives, hipStream_t stream, BuildWorkspace *ws,
+               const Bbox *leaf_src, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms);
+
+// Leaf boxes of a triangle mesh (w = 1), the device counterpart of src/scene/mesh.cpp:88-98.
+int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);
+
+// Packs a finished build into 64-byte traversal records.  out_tris == nullptr selects the top
+// level (leaf references carry instance ids); otherwise triangle records are written in sorted
+// leaf order.  `root` is a device pointer.
+int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const AccelNode *nodes, const Bbox *bboxes, uint32_t num_primitives,
+              const uint32_t *indices, const V3 *positions, hipStream_t stream);
+
+}  // namespace cpt

@@ -1,0 +1,22 @@
+// Host launchers of the traversal / bounce-loop kernels (render.hip).  All return 0 or a hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace cpt {
+
+// One sample per pixel into p.output: kernel::PathTracer::Render (src/kernels/integrator/path.cuh:22)
+// without the trailing device synchronisation.
+int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream);
+
+// rays: device array of n * 8 floats (origin.xyz, tmin, direction.xyz, tmax).
+// inst/prim receive 0xffffffff on a miss; t receives the hit distance (or the input tmax);
+// t and uv may be null.
+int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, hipStream_t stream);
+int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *out, hipStream_t stream);
+
+// Camera rays of 1-based sample index spp for every pixel, stored in pixel-index order (row 0 = top).
+int launch_camera_rays(const CameraDev &cam, uint32_t W, uint32_t H, uint32_t spp, float *rays, hipStream_t stream);
+
+}  // namespace cpt

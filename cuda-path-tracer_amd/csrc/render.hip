@@ -1,0 +1,266 @@
+// Megakernel path tracer for gfx950: one lane = one pixel = one path per launch, the direct
+// counterpart of RenderKernel/Trace (src/kernels/integrator/path.cu:9-105), plus the batch
+// first-hit / any-hit / camera-ray kernels used by the parity tests and the benchmark.
+#include "render.h"
+
+#include <hip/hip_runtime.h>
+
+#include "shading.h"
+#include "trace.h"
+
+namespace cpt {
+
+namespace {
+
+struct Surface { Vertex vertex; BsdfDev bsdf; int32_t light; };
+
+// src/kernels/scene/instance.cuh:19-26
+__device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit) {
+    const InstanceDev &in = sc.instances[hit.inst];
+    const MeshDev &m = sc.meshes[in.mesh];
+    Surface s;
+    s.vertex = get_vertex(m, hit.prim, hit.u, hit.v);
+    M4 tr = in.transform;
+    vertex_transform_pdf(s.vertex, tr);
+    s.vertex.position = xyz(mul(tr, v4(s.vertex.position, 1.0f)));
+    s.vertex.normal = xyz(normalize4(mul(in.transform_it, v4(s.vertex.normal, 0.0f))));   // 4-component normalise, as the reference writes it
+    s.bsdf = sc.materials[in.material];
+    s.light = in.light;
+    return s;
+}
+
+struct LightSample { V3 dir; float pdf; V3 weight; float dist; };
+
+// src/kernels/geometry/geometry.cuh:27-39 + src/kernels/light/geometry.cuh:17-30
+__device__ inline LightSample light_sample(const SceneDev &sc, uint32_t inst_id, V3 pos, V2 rand) {
+    const InstanceDev &in = sc.instances[inst_id];
+    const MeshDev &m = sc.meshes[in.mesh];
+    Vertex vert = sample_vertex(m, rand);
+    M4 tr = in.transform;
+    vertex_transform_pdf(vert, tr);
+    vert.position = xyz(mul(tr, v4(vert.position, 1.0f)));
+    vert.normal = xyz(normalize4(mul(in.transform_it, v4(vert.normal, 0.0f))));
+    V3 vec = vert.position - pos;
+    float dist_sqr = dot(vec, vec);
+    float dist = sqrtf(dist_sqr);
+    V3 dir = vec / dist;
+    LightSample ls;
+    ls.dir = dir;
+    ls.dist = dist;
+    float cos_theta = dot(-dir, vert.normal);
+    ls.pdf = cos_theta > 0.0f ? vert.pdf * dist_sqr / cos_theta : 0.0f;
+    ls.weight = sc.materials[in.material].emission / ls.pdf;
+    return ls;
+}
+
+constexpr float kRayTMin = 0.0001f;          // src/kernels/basic/ray.cuh:8-10
+constexpr float kRayTMax = 3.402823466e+38f;
+constexpr float kShadowRayEps = 0.001f;
+
+// src/kernels/integrator/path.cu:9-83
+__device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, TraceStack &st, LaneCounters &cnt) {
+    Hit hit;
+    float tmax = kRayTMax;
+    if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
+    Surface surface = shading_surface(sc, hit);
+    if (channel == 1) return surface.vertex.normal * 0.5f + v3(0.5f);
+    V3 color = surface.bsdf.emission;
+    if (!is_zero(color)) return color;
+    V3 throughput = v3(1.0f);
+    for (uint32_t depth = 0; depth < max_depth; depth++) {
+        Frame frame = Frame::from_normal(surface.vertex.normal);
+        V3 wo = frame.to_local(-rd);
+
+        if (!bsdf_is_delta(surface.bsdf)) {
+            float r1 = sampler.next1d();
+            uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);   // light/light.cuh:39-43
+            V2 r2 = sampler.next2d();
+            LightSample ls = light_sample(sc, sc.lights[index], surface.vertex.position, r2);
+            ls.pdf *= sc.light_pick_pdf;
+            ls.weight = ls.weight / sc.light_pick_pdf;
+            if (ls.pdf > 0.0f) {
+                Hit dummy;
+                float smax = ls.dist - kShadowRayEps;
+                if (!trace<true>(sc, surface.vertex.position, ls.dir, kRayTMin, smax, dummy, st, cnt)) {
+                    V3 wi = frame.to_local(ls.dir);
+                    float bp = bsdf_pdf(surface.bsdf, wo, wi);
+                    float mis_weight = power_heuristic(ls.pdf, bp);      // area lights are never delta
+                    color = color + throughput * mis_weight * ls.weight * bsdf_eval(surface.bsdf, wo, wi);
+                }
+            }
+        }
+
+        float b1 = sampler.next1d();
+        V2 b2 = sampler.next2d();
+        BsdfSample bs = bsdf_sample(surface.bsdf, wo, b1, b2);
+        if (bs.pdf == 0.0f) break;
+        throughput = throughput * bs.weight;
+        ro = surface.vertex.position;
+        rd = frame.to_world(bs.wi);
+        tmax = kRayTMax;
+        if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) break;
+
+        surface = shading_surface(sc, hit);
+        if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
+            float mis_weight = 1.0f;
+            if (bs.lobe != kLobeSpecular) {
+                float light_pdf = surface.vertex.pdf * path_to_solid_angle_jacobian(ro, surface.vertex.position, surface.vertex.normal) *
+                                  sc.light_pick_pdf;
+                mis_weight = power_heuristic(bs.pdf, light_pdf);
+            }
+            color = color + throughput * mis_weight * surface.bsdf.emission;
+            break;
+        }
+
+        float rr_prop = gmin(gmax(luminance(throughput), 0.01f), 0.95f);
+        if (sampler.next1d() > rr_prop) break;
+        throughput = throughput / rr_prop;
+    }
+    return color;
+}
+
+__device__ inline void flush_counters(const SceneDev &sc, const LaneCounters &cnt, uint32_t paths, unsigned long long *block_cnt) {
+    if (!sc.counters) return;
+    if (threadIdx.x < 4) block_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    atomicAdd(&block_cnt[0], (unsigned long long)cnt.rays);
+    atomicAdd(&block_cnt[1], (unsigned long long)cnt.nodes);
+    atomicAdd(&block_cnt[2], (unsigned long long)cnt.tris);
+    atomicAdd(&block_cnt[3], (unsigned long long)paths);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sc.counters->rays, block_cnt[0]);
+        atomicAdd(&sc.counters->node_visits, block_cnt[1]);
+        atomicAdd(&sc.counters->tri_tests, block_cnt[2]);
+        atomicAdd(&sc.counters->paths, block_cnt[3]);
+    }
+}
+
+// Workgroups are dealt to the 8 XCDs round robin; give each XCD one contiguous band of tiles so
+// that neighbouring tiles, which walk the same part of the BVH, share an L2.
+__device__ inline uint32_t xcd_band_remap(uint32_t b, uint32_t nb) {
+    uint32_t q = nb / 8, r = nb % 8, xcd = b % 8, k = b / 8;
+    uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+// one workgroup = one 16x16 pixel tile, one wave = one 8x8 sub-tile
+__global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParams p) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[4];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    const uint32_t tiles_x = (p.width + 15) / 16;
+    const uint32_t tile = xcd_band_remap(blockIdx.x, gridDim.x);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t px = (tile % tiles_x) * 16 + (w & 1) * 8 + (lane & 7);
+    const uint32_t py = (tile / tiles_x) * 16 + (w >> 1) * 8 + (lane >> 3);
+    const bool active = px < p.width && py < p.height;
+    if (active) {
+        Sampler sampler;
+        uint32_t pixel_index;
+        V3 ro, rd;
+        pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
+        V3 color = trace_path(sc, ro, rd, sampler, p.max_depth, p.channel, st, cnt);
+        if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
+        float4 *out = reinterpret_cast<float4 *>(p.output) + pixel_index;
+        float4 prev = *out;
+        float4 res;
+        if (p.sum_mode) {
+            res = make_float4(prev.x + color.x, prev.y + color.y, prev.z + color.z, prev.w + 1.0f);
+        } else {
+            float a = 1.0f / (float)p.spp;      // glm::mix(prev, new, a) = prev * (1 - a) + new * a  (path.cu:102-104)
+            res = make_float4(prev.x * (1.0f - a) + color.x * a, prev.y * (1.0f - a) + color.y * a, prev.z * (1.0f - a) + color.z * a,
+                              prev.w * (1.0f - a) + 1.0f * a);
+        }
+        *out = res;
+    }
+    flush_counters(sc, cnt, active ? 1u : 0u, s_cnt);
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
+                                                            uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[4];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i < n) {
+        const float4 *r = reinterpret_cast<const float4 *>(rays) + 2 * i;
+        float4 a = r[0], b = r[1];
+        Hit hit;
+        float tmax = b.w;
+        bool ok = trace<false>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
+        inst_out[i] = ok ? hit.inst : 0xffffffffu;
+        prim_out[i] = ok ? hit.prim : 0xffffffffu;
+        if (t_out) t_out[i] = tmax;
+        if (uv_out) { uv_out[2 * i] = ok ? hit.u : 0.0f; uv_out[2 * i + 1] = ok ? hit.v : 0.0f; }
+    }
+    flush_counters(sc, cnt, 0u, s_cnt);
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[4];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i < n) {
+        const float4 *r = reinterpret_cast<const float4 *>(rays) + 2 * i;
+        float4 a = r[0], b = r[1];
+        Hit hit;
+        float tmax = b.w;
+        out[i] = trace<true>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
+    }
+    flush_counters(sc, cnt, 0u, s_cnt);
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_camera_rays(CameraDev cam, uint32_t W, uint32_t H, uint32_t spp, float *__restrict__ rays) {
+    uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i >= W * H) return;
+    uint32_t px = i % W, py = i / W;
+    Sampler s;
+    uint32_t pixel_index;
+    V3 o, d;
+    pixel_ray(cam, W, H, px, py, spp, s, pixel_index, o, d);
+    float4 *r = reinterpret_cast<float4 *>(rays) + 2 * (size_t)pixel_index;
+    r[0] = make_float4(o.x, o.y, o.z, kRayTMin);
+    r[1] = make_float4(d.x, d.y, d.z, kRayTMax);
+}
+
+}  // namespace
+
+int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream) {
+    uint32_t tiles = ((p.width + 15) / 16) * ((p.height + 15) / 16);
+    if (tiles == 0) return 0;
+    hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
+    return (int)hipGetLastError();
+}
+
+int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, hipStream_t stream) {
+    if (n == 0) return 0;
+    uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+    if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_first_hit, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
+    return (int)hipGetLastError();
+}
+
+int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *out, hipStream_t stream) {
+    if (n == 0) return 0;
+    uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+    if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_occlude, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
+    return (int)hipGetLastError();
+}
+
+int launch_camera_rays(const CameraDev &cam, uint32_t W, uint32_t H, uint32_t spp, float *rays, hipStream_t stream) {
+    uint64_t n = (uint64_t)W * H;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_camera_rays, dim3((uint32_t)((n + kTraceBlock - 1) / kTraceBlock)), dim3(kTraceBlock), 0, stream, cam, W, H, spp, rays);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cpt

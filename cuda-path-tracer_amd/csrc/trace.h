@@ -1,0 +1,151 @@
+// Two-level BVH traversal and ray/triangle intersection for gfx950 (device code).
+//
+// Bit-exact against the reference traversal (src/kernels/accel/accel.cuh:33-173 and
+// src/kernels/geometry/trimesh.cuh:14-43):
+//  * same slab arithmetic: six true IEEE divisions per box, compare-and-swap ordering, fmax/fmin
+//    NaN rules, hit <=> t0 <= t1 && t0 < tmax && t1 > tmin;
+//  * same visit order: the reference pushes the left child, then the right one, and pops the
+//    right one first, testing a node's box when it is POPPED (accel.cuh:73-86).  Here both child
+//    boxes arrive with their parent's 64-byte record, so the tmax-independent part of the test
+//    (t0 <= t1 && t1 > tmin) is evaluated at the parent and the entry point t0 is kept with a
+//    deferred left child; `t0 < tmax` is re-checked when that child is popped, which is the
+//    decision the reference takes at that moment because t0 and t1 depend only on box and ray;
+//  * same Moeller-Trumbore expression order, two-sided, strict tmin < t < tmax acceptance.
+// Rays are not renormalised when they enter an instance, so t is shared between spaces
+// (accel.cuh:54-59).
+#pragma once
+#include "device_types.h"
+
+namespace cpt {
+
+constexpr int kLdsStackEntries = 24;   // per lane, in LDS: 24 * 8 B * 256 lanes = 48 KB per workgroup
+constexpr int kSpillEntries = 40;      // per lane, private memory, touched only by very deep trees
+constexpr int kTraceBlock = 256;
+
+struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0; };
+
+// Per-lane stack of (node reference, entry distance) pairs.  Entry e of lane l lives at
+// lds[e * 256 + l]: lanes of a wave always touch consecutive 8-byte slots, whatever their depths.
+struct TraceStack {
+    uint2 *lds;
+    uint2 spill[kSpillEntries];
+    __device__ inline void push(uint32_t sp, uint32_t node, float t0) {
+        uint2 e = make_uint2(node, __float_as_uint(t0));
+        if (sp < kLdsStackEntries) lds[sp * kTraceBlock + threadIdx.x] = e;
+        else if (sp < kLdsStackEntries + kSpillEntries) spill[sp - kLdsStackEntries] = e;
+    }
+    __device__ inline uint2 at(uint32_t sp) const {
+        if (sp < kLdsStackEntries) return lds[sp * kTraceBlock + threadIdx.x];
+        if (sp < kLdsStackEntries + kSpillEntries) return spill[sp - kLdsStackEntries];
+        return make_uint2(0u, 0x7fc00000u);   // NaN entry distance: never entered
+    }
+};
+
+struct Hit { uint32_t inst, prim; float u, v; };
+
+// accel.cuh:33-52 without the tmax clause; returns the entry distance in t0
+__device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, V3 o, V3 d, float tmin, float &t0) {
+    float x0 = (bminx - o.x) / d.x;
+    float x1 = (bmaxx - o.x) / d.x;
+    float xa = x0 > x1 ? x1 : x0, xb = x0 > x1 ? x0 : x1;
+    float y0 = (bminy - o.y) / d.y;
+    float y1 = (bmaxy - o.y) / d.y;
+    float ya = y0 > y1 ? y1 : y0, yb = y0 > y1 ? y0 : y1;
+    float z0 = (bminz - o.z) / d.z;
+    float z1 = (bmaxz - o.z) / d.z;
+    float za = z0 > z1 ? z1 : z0, zb = z0 > z1 ? z0 : z1;
+    t0 = fmaxf(xa, fmaxf(ya, za));
+    float t1 = fminf(xb, fminf(yb, zb));
+    return t0 <= t1 && t1 > tmin;
+}
+
+// trimesh.cuh:14-43 on a pre-gathered record
+__device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim) {
+    const float4 *q = reinterpret_cast<const float4 *>(rec);
+    float4 a = q[0], b = q[1], c = q[2];
+    V3 p0 = v3(a.x, a.y, a.z), e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+    V3 qv = cross(d, e2);
+    float det = dot(e1, qv);
+    if (det != 0.0f) {
+        det = 1.0f / det;
+        V3 s = o - p0;
+        float v = dot(s, qv) * det;
+        if (v >= 0.0f) {
+            V3 r = cross(s, e1);
+            float w = dot(d, r) * det;
+            float u = 1.0f - v - w;
+            if (w >= 0.0f && u >= 0.0f) {
+                float tt = dot(e2, r) * det;
+                if (tt > tmin && tt < tmax) {
+                    t = tt; bv = v; bw = w; prim = __float_as_uint(a.w);
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
+// Closest hit (ANY = false; AccelTop::Intersect, accel.cuh:124-150) or any hit (ANY = true;
+// AccelTop::Occlude, accel.cuh:152-173).  tmax is updated to the hit distance on closest hits.
+template <bool ANY>
+__device__ inline bool trace(const SceneDev &sc, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
+    cnt.rays++;
+    const AccelRoot troot = *sc.top_root;
+    float t0;
+    if (!(slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], ow, dw, tmin, t0) && t0 < tmax))
+        return false;
+    uint32_t cur = troot.ref;
+    bool in_blas = false, found = false;
+    uint32_t sp = 0, sp_base = 0, inst_id = 0;
+    V3 o = ow, d = dw;
+    const PackedNode *nodes = sc.top_nodes;
+    const TriRecord *tris = nullptr;
+    for (;;) {
+        if (!(cur & kLeafBit)) {
+            const float4 *q = reinterpret_cast<const float4 *>(nodes + cur);
+            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            cnt.nodes++;
+            float t0l, t0r;
+            bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tmin, t0l);
+            bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tmin, t0r);
+            if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+            if (hr && t0r < tmax) { cur = __float_as_uint(q3.y); continue; }
+        } else if (in_blas) {
+            float t, bv, bw;
+            uint32_t prim;
+            cnt.tris++;
+            if (tri_test(tris + (cur & ~kLeafBit), o, d, tmin, tmax, t, bv, bw, prim)) {
+                if (ANY) return true;
+                tmax = t;
+                hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                found = true;
+            }
+        } else {
+            inst_id = cur & ~kLeafBit;
+            const InstanceDev &in = sc.instances[inst_id];
+            M4 inv = in.transform_inv;
+            o = xyz(mul(inv, v4(ow, 1.0f)));
+            d = xyz(mul(inv, v4(dw, 0.0f)));
+            const MeshDev &m = sc.meshes[in.mesh];
+            nodes = m.nodes;
+            tris = m.tris;
+            AccelRoot r = m.root;
+            in_blas = true;
+            sp_base = sp;
+            if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], o, d, tmin, t0) && t0 < tmax) {
+                cur = r.ref;
+                continue;
+            }
+        }
+        for (;;) {
+            if (in_blas && sp == sp_base) { in_blas = false; o = ow; d = dw; nodes = sc.top_nodes; }
+            if (sp == 0) return found;
+            --sp;
+            uint2 e = st.at(sp);
+            if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+        }
+    }
+}
+
+}  // namespace cpt

@@ -1,0 +1,147 @@
+/* C ABI of libcpt_amd.so: the MI355X (gfx950) implementation of the path tracer's data-parallel
+ * core -- LBVH build, BVH traversal / ray-triangle intersection, path-tracing bounce loop.
+ *
+ * The reference (PepcyCh/cuda-path-tracer) has no FFI of its own; each entry point below names
+ * the C++ entry point of the reference it stands for.  Conventions:
+ *   - every function returns 0 on success and a negative code on failure (or a pointer / count
+ *     where stated); cpt_last_error() returns a message for the calling thread's last failure;
+ *   - pointers named d_* are DEVICE pointers on the current device, all others are host pointers;
+ *   - a ray is 8 floats: origin.xyz, tmin, direction.xyz, tmax       (src/kernels/basic/ray.cuh:7-20)
+ *   - a box is 8 floats: pmin.xyzw, pmax.xyzw                        (src/kernels/accel/accel.cuh:15-18)
+ *   - a node is 2 uint32: lc_or_id, rc; rc == 0xffffffff marks a leaf (src/kernels/accel/accel.cuh:20-23)
+ *   - matrices are 16 floats, column major (glm::mat4)
+ *   - a material is 16 floats: emission[3] diffuse[3] specular[3] transmittance[3] shininess ior
+ *     opacity bsdf_type (0 lambert, 1 phong, 2 blinn-phong, 3 microfacet)  (src/scene/material.hpp:25-32)
+ *   - images are W*H*4 floats (RGBA), row 0 = top of the image        (src/kernels/integrator/path.cu:90)
+ * Handles are not thread safe; use one tracer per host thread / device.
+ */
+#ifndef CPT_AMD_H
+#define CPT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPT_OK 0
+#define CPT_ERR_INVALID (-1)   /* bad argument or state */
+#define CPT_ERR_DEVICE (-2)    /* HIP runtime failure (no device, out of memory, launch failure) */
+#define CPT_ERR_IO (-3)        /* file missing or malformed */
+
+typedef struct cpt_scene cpt_scene;    /* host scene: objects with mesh + material, one camera   */
+typedef struct cpt_tracer cpt_tracer;  /* PathTracer + Film bound to one scene on one device     */
+
+const char *cpt_last_error(void);
+int cpt_device_count(void);            /* number of HIP devices, 0 when there is none */
+int cpt_set_device(int device);
+
+/* ---- device memory helpers, so that a C caller needs no HIP headers -------------------------- */
+void *cpt_malloc(size_t bytes);        /* NULL on failure */
+int cpt_free(void *d_ptr);
+int cpt_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
+int cpt_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
+int cpt_memset(void *d_dst, int value, size_t bytes);
+int cpt_synchronize(void);
+
+/* ---- (1) LBVH builder ------------------------------------------------------------------------
+ * Replaces: void kernel::BuildAccel(AccelNode *nodes, Bbox *bboxes, Bbox merged_bbox,
+ *                                   uint32_t num_primitives)   src/kernels/accel/accel_build.cuh:7
+ * d_nodes / d_bboxes hold 2n-1 entries; the n leaf boxes are pre-filled at [n-1, 2n-1) and are
+ * reordered in place; all nodes and the n-1 internal boxes are written.  Scratch memory is
+ * allocated and freed inside the call, which returns after the build has completed. */
+int cpt_build_accel(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives);
+
+/* Same build with the intermediate arrays exposed for parity checks and profiling (all optional):
+ *   d_keys_out    n sorted 64-bit keys, (morton30 << 32) | primitive index
+ *   d_parents_out 2n-1 parent indices (entry 0 is never written, as in the reference)
+ *   stage_ms      host array of 5: morton, sort, gather, karras, refit milliseconds */
+int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives, uint64_t *d_keys_out,
+                       uint32_t *d_parents_out, float *stage_ms);
+
+/* Reusable-scratch variant for timing loops: the scratch lives in the handle, no allocation
+ * happens after the first call of a given size, and the call only enqueues work (synchronise with
+ * cpt_synchronize).  elapsed_ms (optional) receives the device time of this build and forces a sync. */
+typedef struct cpt_builder cpt_builder;
+cpt_builder *cpt_builder_create(void);
+void cpt_builder_destroy(cpt_builder *b);
+int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
+                      uint32_t num_primitives, float *elapsed_ms, float *stage_ms);
+
+/* ---- scene description -----------------------------------------------------------------------
+ * Replaces: Scene, SceneObject, Mesh, Material, CameraComponent   src/scene/core.hpp:116-240,
+ *           src/scene/mesh.hpp, src/scene/material.hpp, src/scene/camera.hpp
+ *           LoadObjScene / LoadJsonScene / LoadXmlScene            src/scene/loader.hpp:7-11 */
+cpt_scene *cpt_scene_create(void);
+void cpt_scene_destroy(cpt_scene *s);
+int cpt_scene_load_obj(cpt_scene *s, const char *path, int bsdf_type);
+int cpt_scene_load_json(cpt_scene *s, const char *path);
+int cpt_scene_load_xml(cpt_scene *s, const char *path);
+/* adds one object (mesh + material); transform16 may be NULL (identity) */
+int cpt_scene_add_object(cpt_scene *s, const char *name, const float *positions, const float *normals, const float *texcoords,
+                         uint32_t num_vertices, const uint32_t *indices, uint32_t num_triangles, const float material16[16],
+                         const float *transform16);
+int cpt_scene_set_camera(cpt_scene *s, const float pos[3], const float look_at[3], const float up[3], float fov_degrees,
+                         uint32_t film_width, uint32_t film_height);
+/* introspection (used by the parity tests to feed the same arrays to the CPU oracle) */
+uint32_t cpt_scene_num_objects(const cpt_scene *s);                 /* objects that carry a mesh */
+int cpt_scene_object_info(const cpt_scene *s, uint32_t index, char *name_buf, size_t name_buf_size, uint32_t *num_vertices,
+                          uint32_t *num_triangles, float material16[16], float transform16[16]);
+int cpt_scene_object_copy(const cpt_scene *s, uint32_t index, float *positions, float *normals, float *texcoords, uint32_t *indices);
+/* cam10: pos[3] look_at[3] up[3] fov; res2: film width, height.  CPT_ERR_INVALID without a camera */
+int cpt_scene_camera(const cpt_scene *s, float cam10[10], uint32_t res2[2]);
+
+/* ---- (2)+(3) traversal and bounce loop -------------------------------------------------------
+ * Replaces: PathTracer(Scene&, Film&), BuildBuffers, Update, ResetAccumelation, SetMaxDepth
+ *           src/pathtracer/pathtracer.hpp:7-50, and Film  src/pathtracer/film.hpp:6-30,
+ *           which drive kernel::PathTracer::Render          src/kernels/integrator/path.cuh:22 */
+cpt_tracer *cpt_tracer_create(cpt_scene *s, uint32_t film_width, uint32_t film_height);
+void cpt_tracer_destroy(cpt_tracer *t);
+int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth);         /* -1 = unbounded, Russian roulette only */
+int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour, 1 shading normal */
+int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
+int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */
+int cpt_tracer_update(cpt_tracer *t);                               /* PathTracer::Update: one more sample per pixel (asynchronous) */
+int cpt_tracer_reset_accumulation(cpt_tracer *t);                   /* PathTracer::ResetAccumelation + cleared film */
+int cpt_tracer_synchronize(cpt_tracer *t);
+uint32_t cpt_tracer_current_spp(const cpt_tracer *t);
+uint32_t cpt_tracer_num_lights(const cpt_tracer *t);
+/* Sharded rendering: sample indices [spp_begin, spp_begin + spp_count), 1-based like the
+ * reference's spp counter, each an independent random stream (seeded by pixel and sample index,
+ * src/kernels/integrator/path.cu:92).  sum_mode = 1 accumulates plain sums (alpha counts samples)
+ * so that buffers of different devices can be added; sum_mode = 0 keeps the reference's running
+ * mean.  d_output (W*H*4 floats) may be NULL to use the tracer's film.  Asynchronous. */
+int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_count, int sum_mode, float *d_output, uint32_t width,
+                              uint32_t height);
+float *cpt_tracer_film_device_ptr(cpt_tracer *t);                   /* Film::CudaMap */
+int cpt_tracer_film_read(cpt_tracer *t, float *rgba);               /* synchronises */
+int cpt_tracer_film_save(cpt_tracer *t, const char *path);          /* Film::SaveTo: fp32 RGBA OpenEXR */
+
+/* Batch ray queries against the built scene (AccelTop::Intersect / AccelTop::Occlude,
+ * src/kernels/accel/accel.cuh:124-173).  Outputs: instance id and ORIGINAL primitive id
+ * (0xffffffff on a miss), hit distance (input tmax on a miss), barycentrics (v, w).  d_t and d_uv
+ * may be NULL.  Asynchronous on the tracer's stream. */
+int cpt_tracer_first_hit(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint32_t *d_instance, uint32_t *d_primitive, float *d_t,
+                         float *d_uv);
+int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint8_t *d_occluded);
+/* camera rays of sample index spp for a width*height image, in pixel-index order */
+int cpt_tracer_camera_rays(cpt_tracer *t, uint32_t width, uint32_t height, uint32_t spp, float *d_rays);
+
+/* Finished build arrays in the reference layout, copied to the host: mesh < 0 selects the
+ * top-level structure, otherwise the bottom-level structure of object `mesh`.  nodes: 2*(2n-1)
+ * uint32, bboxes: 8*(2n-1) floats, keys: n uint64; any of them may be NULL.  Returns n. */
+int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bboxes, uint64_t *keys);
+/* counters since the last reset: rays (closest + any hit queries), 64-byte node records
+ * fetched, triangle records fetched, camera paths started */
+int cpt_tracer_counters(cpt_tracer *t, uint64_t out4[4]);
+int cpt_tracer_reset_counters(cpt_tracer *t);
+int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
+
+/* Standalone OpenEXR writer used by Film::SaveTo (src/pathtracer/film.cpp:61-68). */
+int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPT_AMD_H */

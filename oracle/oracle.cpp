@@ -1,0 +1,1380 @@
+// TEST INFRASTRUCTURE ONLY -- never linked, imported or called by the product path.
+//
+// CPU restatement of the reference path tracer's data-parallel core:
+//   LBVH build        -> /root/reference/src/kernels/accel/accel_build.cu
+//   traversal         -> /root/reference/src/kernels/accel/accel.cuh
+//   ray/triangle      -> /root/reference/src/kernels/geometry/trimesh.cuh
+//   bounce loop       -> /root/reference/src/kernels/integrator/path.cu
+// plus the host-side table builders that feed them (src/scene/mesh.cpp,
+// src/pathtracer/pathtracer.cpp, src/scene/camera.cpp, src/scene/bbox.cpp).
+//
+// Arithmetic convention: IEEE fp32, no contraction (build with -ffp-contract=off),
+// correctly rounded divide/sqrt, glm 0.9.9.8 expression order (dot = x+y+z left to
+// right, vec4 dot = (x+y)+(z+w), mat4*vec4 = (m0*x+m1*y)+(m2*z+m3*w)), random draws
+// taken left to right where the reference leaves argument order unspecified.
+//
+// Pinning: traversal, triangle test, vertex fetch, BSDFs, sampler and camera are
+// checked against the reference's own headers compiled in oracle/_ref (see
+// ref_driver.cpp).  The LBVH builder and the Trace/RenderKernel glue live in .cu
+// files that need the CUDA toolkit (launch syntax, thrust, cuda_runtime) and are
+// NOT buildable here: for those two pieces parity is pinned only by the node arrays
+// and image statistics recorded from the reference during the survey
+// (tests/golden/cornell_lbvh.json) -- otherwise "parity unpinned".
+#include <cmath>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <cfloat>
+#include <vector>
+#include <algorithm>
+#include <thread>
+#include <atomic>
+#include <limits>
+
+namespace {
+
+// ------------------------------------------------------------------ vector math (glm semantics)
+struct V2 { float x, y; };
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+struct M4 { V4 c[4]; };  // column major, c[i] = column i (glm mat4)
+
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline bool operator==(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+inline bool operator!=(V3 a, V3 b) { return !(a == b); }
+inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+inline V2 operator-(V2 a, V2 b) { return {a.x - b.x, a.y - b.y}; }
+inline V2 operator*(float s, V2 a) { return {s * a.x, s * a.y}; }
+inline V4 operator+(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline V4 operator*(V4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+
+// thirdparty/glm/glm/detail/func_geometric.inl:48-66
+inline float dot(V3 a, V3 b) { V3 t = a * b; return t.x + t.y + t.z; }
+inline float dot4(V4 a, V4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+// func_geometric.inl:68-79
+inline V3 cross(V3 x, V3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline float inversesqrt(float x) { return 1.0f / std::sqrt(x); }
+inline V3 normalize(V3 v) { return v * inversesqrt(dot(v, v)); }
+inline V4 normalize4(V4 v) { return v * inversesqrt(dot4(v, v)); }
+inline float length(V3 v) { return std::sqrt(dot(v, v)); }
+inline float gmin(float a, float b) { return (b < a) ? b : a; }   // glm::min
+inline float gmax(float a, float b) { return (a < b) ? b : a; }   // glm::max
+inline V3 gmin3(V3 a, V3 b) { return {gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)}; }
+inline V3 gmax3(V3 a, V3 b) { return {gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)}; }
+
+// thirdparty/glm/glm/detail/type_mat4x4.inl:561-572
+inline V4 mul(const M4 &m, V4 v) {
+    V4 mul0 = m.c[0] * v.x, mul1 = m.c[1] * v.y;
+    V4 add0 = mul0 + mul1;
+    V4 mul2 = m.c[2] * v.z, mul3 = m.c[3] * v.w;
+    V4 add1 = mul2 + mul3;
+    return add0 + add1;
+}
+inline V3 xyz(V4 v) { return {v.x, v.y, v.z}; }
+// mat3(m) * v : type_mat3x3.inl (row sums left to right)
+inline V3 mul3(const M4 &m, V3 v) {
+    return {m.c[0].x * v.x + m.c[1].x * v.y + m.c[2].x * v.z,
+            m.c[0].y * v.x + m.c[1].y * v.y + m.c[2].y * v.z,
+            m.c[0].z * v.x + m.c[1].z * v.y + m.c[2].z * v.z};
+}
+inline M4 transpose(const M4 &m) {
+    M4 r;
+    r.c[0] = {m.c[0].x, m.c[1].x, m.c[2].x, m.c[3].x};
+    r.c[1] = {m.c[0].y, m.c[1].y, m.c[2].y, m.c[3].y};
+    r.c[2] = {m.c[0].z, m.c[1].z, m.c[2].z, m.c[3].z};
+    r.c[3] = {m.c[0].w, m.c[1].w, m.c[2].w, m.c[3].w};
+    return r;
+}
+// general 4x4 inverse by cofactors (host side only; identity for every shipped scene)
+M4 inverse(const M4 &mm) {
+    const float *m = &mm.c[0].x;
+    double inv[16], a[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
+    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
+    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
+    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
+    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
+    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
+    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
+    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
+    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
+    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
+    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
+    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
+    double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+    M4 r;
+    float *o = &r.c[0].x;
+    for (int i = 0; i < 16; i++) {
+        double v = inv[i] / det;
+        o[i] = (v == 0.0) ? 0.0f : (float)v;   // no negative zeros
+    }
+    return r;
+}
+
+constexpr float kPi = 3.14159265359f;          // basic/prelude.cuh:19-22
+constexpr float k2Pi = 2.0f * kPi;
+constexpr float kInvPi = 1.0f / kPi;
+constexpr float kInv2Pi = 1.0f / k2Pi;
+
+// basic/prelude.cuh:24-26 -- the first two products and both sums are double
+inline float Luminance(V3 c) {
+    return (float)((double)c.x * 0.299 + (double)c.y * 0.587 + (double)(c.z * 0.114f));
+}
+
+// ------------------------------------------------------------------ LBVH build (accel_build.cu)
+struct Bbox { V4 pmin, pmax; };            // accel.cuh:15-18
+struct Node { uint32_t lc_or_id, rc; };    // accel.cuh:20-23
+
+constexpr float kMortonCodeResolution = 1024.0f;   // accel_build.cu:13
+
+// accel_build.cu:17-23
+inline uint32_t MortonCode3(uint32_t x) {
+    x = (x ^ (x << 16)) & 0xff0000ff;
+    x = (x ^ (x << 8)) & 0x0300f00f;
+    x = (x ^ (x << 4)) & 0x030c30c3;
+    x = (x ^ (x << 2)) & 0x09249249;
+    return x;
+}
+
+// float -> uint32 as the GPU conversion does it (truncate toward zero, saturate, NaN -> 0)
+inline uint32_t f2u(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+// accel_build.cu:25-41
+inline uint64_t MortonKey(const Bbox &b, const Bbox &merged, uint32_t index) {
+    float cx = (b.pmin.x + b.pmax.x) * 0.5f, cy = (b.pmin.y + b.pmax.y) * 0.5f, cz = (b.pmin.z + b.pmax.z) * 0.5f;
+    float sx = merged.pmax.x - merged.pmin.x, sy = merged.pmax.y - merged.pmin.y, sz = merged.pmax.z - merged.pmin.z;
+    float px = (cx - merged.pmin.x) / sx, py = (cy - merged.pmin.y) / sy, pz = (cz - merged.pmin.z) / sz;
+    uint32_t x = MortonCode3(f2u(std::fmin(px * kMortonCodeResolution, kMortonCodeResolution - 1)));
+    uint32_t y = MortonCode3(f2u(std::fmin(py * kMortonCodeResolution, kMortonCodeResolution - 1)));
+    uint32_t z = MortonCode3(f2u(std::fmin(pz * kMortonCodeResolution, kMortonCodeResolution - 1)));
+    uint64_t morton_code = (x << 2) | (y << 1) | z;
+    return (morton_code << 32) | index;
+}
+
+// accel_build.cu:53-55
+// __clzll(0) is 64 on the GPU (reached when a node's first key is compared with itself)
+inline uint32_t Lcp(uint64_t a, uint64_t b) { uint64_t x = a ^ b; return x ? (uint32_t)__builtin_clzll(x) : 64u; }
+
+// accel_build.cu:57-95
+void FindNodeRange(uint32_t index, const uint64_t *codes, uint32_t n, uint32_t &first, uint32_t &last) {
+    if (index == 0) { first = 0; last = n - 1; return; }
+    uint64_t code = codes[index];
+    uint32_t l_lcp = Lcp(code, codes[index - 1]);
+    uint32_t r_lcp = Lcp(code, codes[index + 1]);
+    int d = l_lcp > r_lcp ? -1 : 1;
+    uint32_t min_lcp = l_lcp < r_lcp ? l_lcp : r_lcp;
+    uint32_t step = 1;
+    uint32_t j_lcp;
+    do {
+        step <<= 1;
+        int j = (int)(index + (uint32_t)d * step);
+        j_lcp = 0;
+        if (j >= 0 && (uint32_t)j < n) j_lcp = Lcp(code, codes[j]);
+    } while (j_lcp > min_lcp);
+    uint32_t l = step >> 1;
+    uint32_t room = d == -1 ? index : n - 1 - index;
+    uint32_t r = step < room ? step : room;
+    while (l < r) {
+        uint32_t mid = l + ((r - l) >> 1) + 1;
+        uint32_t j = index + (uint32_t)d * mid;
+        uint32_t lcp = Lcp(code, codes[j]);
+        if (lcp < min_lcp) r = mid - 1; else l = mid;
+    }
+    r = index + (uint32_t)d * l;
+    l = index;
+    if (l <= r) { first = l; last = r; } else { first = r; last = l; }
+}
+
+// accel_build.cu:97-115
+uint32_t FindNodeLeftChild(uint32_t first, uint32_t last, const uint64_t *codes) {
+    uint64_t l_code = codes[first];
+    uint32_t node_lcp = Lcp(l_code, codes[last]);
+    uint32_t l = first, r = last;
+    while (l < r) {
+        uint32_t mid = l + ((r - l) >> 1);
+        if (Lcp(l_code, codes[mid]) > node_lcp) l = mid + 1; else r = mid;
+    }
+    return l - 1;
+}
+
+inline int32_t f_as_i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+inline uint32_t f_as_u(float f) { uint32_t i; memcpy(&i, &f, 4); return i; }
+// accel_build.cu:150-158 (sign-split integer atomics, executed serially here)
+inline void atomicMinFloat(float *addr, float value) {
+    if (!std::signbit(value)) { int32_t cur = f_as_i(*addr), v = f_as_i(value); if (v < cur) *addr = value; }
+    else { uint32_t cur = f_as_u(*addr), v = f_as_u(value); if (v > cur) *addr = value; }
+}
+inline void atomicMaxFloat(float *addr, float value) {
+    if (!std::signbit(value)) { int32_t cur = f_as_i(*addr), v = f_as_i(value); if (v > cur) *addr = value; }
+    else { uint32_t cur = f_as_u(*addr), v = f_as_u(value); if (v < cur) *addr = value; }
+}
+
+// accel_build.cu:184-206.  nodes/bboxes hold 2n-1 entries, leaves pre-filled at [n-1, 2n-1).
+void BuildAccel(Node *nodes, Bbox *bboxes, Bbox merged, uint32_t n, uint64_t *keys_out, uint32_t *parents_out) {
+    if (n == 0) return;
+    uint32_t ni = n - 1;
+    Bbox *leaf = bboxes + ni;
+    std::vector<uint64_t> codes(n);
+    for (uint32_t i = 0; i < n; i++) codes[i] = MortonKey(leaf[i], merged, i);          // :190-191
+    {                                                                                    // :193 sort_by_key
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
+        std::vector<uint64_t> c2(n);
+        std::vector<Bbox> b2(n);
+        for (uint32_t i = 0; i < n; i++) { c2[i] = codes[order[i]]; b2[i] = leaf[order[i]]; }
+        codes.swap(c2);
+        memcpy(leaf, b2.data(), sizeof(Bbox) * n);
+    }
+    for (uint32_t i = 0; i < n; i++) { nodes[ni + i].lc_or_id = (uint32_t)codes[i]; nodes[ni + i].rc = ~0u; }   // :43-51
+    std::vector<uint32_t> parents(n + ni, 0xffffffffu);
+    for (uint32_t i = 0; i < ni; i++) {                                                  // :117-138
+        uint32_t first, last;
+        FindNodeRange(i, codes.data(), n, first, last);
+        uint32_t lc = FindNodeLeftChild(first, last, codes.data());
+        uint32_t rc = lc + 1;
+        if (lc == first) lc += ni;
+        if (rc == last) rc += ni;
+        nodes[i].lc_or_id = lc;
+        nodes[i].rc = rc;
+        parents[lc] = i;
+        parents[rc] = i;
+    }
+    for (uint32_t i = 0; i < ni; i++) { bboxes[i].pmin = merged.pmax; bboxes[i].pmax = merged.pmin; }   // :140-148
+    for (uint32_t i = 0; i < n; i++) {                                                   // :160-180
+        uint32_t u = ni + i;
+        uint32_t pa = parents[u];
+        Bbox b = bboxes[u];
+        while (u != 0) {
+            atomicMinFloat(&bboxes[pa].pmin.x, b.pmin.x);
+            atomicMinFloat(&bboxes[pa].pmin.y, b.pmin.y);
+            atomicMinFloat(&bboxes[pa].pmin.z, b.pmin.z);
+            atomicMaxFloat(&bboxes[pa].pmax.x, b.pmax.x);
+            atomicMaxFloat(&bboxes[pa].pmax.y, b.pmax.y);
+            atomicMaxFloat(&bboxes[pa].pmax.z, b.pmax.z);
+            u = pa;
+            pa = parents[u];
+        }
+    }
+    if (keys_out) memcpy(keys_out, codes.data(), sizeof(uint64_t) * n);
+    if (parents_out) memcpy(parents_out, parents.data(), sizeof(uint32_t) * (n + ni));
+}
+
+// ------------------------------------------------------------------ rays, traversal, triangles
+struct Ray {                                   // basic/ray.cuh:7-20
+    V3 origin; float tmin = 0.0001f;
+    V3 direction; float tmax = FLT_MAX;
+    Ray() {}
+    Ray(V3 o, V3 d) : origin(o), direction(d) {}
+};
+constexpr float kShadowRayEps = 0.001f;
+
+struct Counters {
+    uint64_t rays = 0;        // AccelTop::Intersect + AccelTop::Occlude calls
+    uint64_t box_tests = 0;   // BboxIntersect calls (TLAS + BLAS)
+    uint64_t tri_tests = 0;   // TriMesh::Intersect calls
+    uint32_t max_stack = 0;   // largest pending-stack occupancy seen
+    void add(const Counters &o) {
+        rays += o.rays; box_tests += o.box_tests; tri_tests += o.tri_tests;
+        if (o.max_stack > max_stack) max_stack = o.max_stack;
+    }
+};
+
+// accel.cuh:33-52
+inline bool BboxIntersect(const V4 &pmin, const V4 &pmax, const Ray &ray) {
+    float x0 = (pmin.x - ray.origin.x) / ray.direction.x;
+    float x1 = (pmax.x - ray.origin.x) / ray.direction.x;
+    if (x0 > x1) std::swap(x0, x1);
+    float y0 = (pmin.y - ray.origin.y) / ray.direction.y;
+    float y1 = (pmax.y - ray.origin.y) / ray.direction.y;
+    if (y0 > y1) std::swap(y0, y1);
+    float z0 = (pmin.z - ray.origin.z) / ray.direction.z;
+    float z1 = (pmax.z - ray.origin.z) / ray.direction.z;
+    if (z0 > z1) std::swap(z0, z1);
+    float t0 = std::fmax(x0, std::fmax(y0, z0));
+    float t1 = std::fmin(x1, std::fmin(y1, z1));
+    return t0 <= t1 && t0 < ray.tmax && t1 > ray.tmin;
+}
+
+// accel.cuh:54-59
+inline Ray TransformRay(const Ray &ray, const M4 &trans) {
+    Ray res = ray;
+    res.origin = xyz(mul(trans, V4{ray.origin.x, ray.origin.y, ray.origin.z, 1.0f}));
+    res.direction = xyz(mul(trans, V4{ray.direction.x, ray.direction.y, ray.direction.z, 0.0f}));
+    return res;
+}
+
+struct Vertex { V3 position; V3 normal; V2 texcoord; float pdf; };   // geometry/common.cuh:8-13
+
+struct Mesh {
+    std::vector<V3> positions, normals;
+    std::vector<V2> texcoords;
+    std::vector<uint32_t> indices;
+    uint32_t num_triangles = 0;
+    std::vector<Node> nodes;      // BLAS
+    std::vector<Bbox> bboxes;
+    std::vector<uint64_t> keys;
+    V3 bb_min, bb_max;            // scene/mesh.cpp:7-12
+
+    // geometry/trimesh.cuh:14-43
+    bool Intersect(const Ray &ray, uint32_t prim, float &t, V2 &attribs) const {
+        uint32_t i0 = indices[prim * 3], i1 = indices[prim * 3 + 1], i2 = indices[prim * 3 + 2];
+        V3 p0 = positions[i0], p1 = positions[i1], p2 = positions[i2];
+        V3 e1 = p1 - p0, e2 = p2 - p0;
+        V3 q = cross(ray.direction, e2);
+        float det = dot(e1, q);
+        if (det != 0.0f) {
+            det = 1.0f / det;
+            V3 s = ray.origin - p0;
+            float v = dot(s, q) * det;
+            if (v >= 0.0f) {
+                V3 r = cross(s, e1);
+                float w = dot(ray.direction, r) * det;
+                float u = 1.0f - v - w;
+                if (w >= 0.0f && u >= 0.0f) {
+                    t = dot(e2, r) * det;
+                    if (t > ray.tmin && t < ray.tmax) { attribs = {v, w}; return true; }
+                }
+            }
+        }
+        return false;
+    }
+
+    // geometry/trimesh.cuh:45-72
+    Vertex GetVertex(uint32_t prim, V2 a) const {
+        uint32_t i0 = indices[prim * 3], i1 = indices[prim * 3 + 1], i2 = indices[prim * 3 + 2];
+        Vertex vert{};
+        V3 pos0 = positions[i0], pos1 = positions[i1], pos2 = positions[i2];
+        V3 e1 = pos1 - pos0, e2 = pos2 - pos0;
+        float area = length(cross(e1, e2)) * 0.5f;
+        vert.pdf = 1.0f / area / num_triangles;
+        vert.position = pos0 + a.x * (pos1 - pos0) + a.y * (pos2 - pos0);
+        V3 n0 = normals[i0], n1 = normals[i1], n2 = normals[i2];
+        vert.normal = normalize(n0 + a.x * (n1 - n0) + a.y * (n2 - n0));
+        V2 t0 = texcoords[i0], t1 = texcoords[i1], t2 = texcoords[i2];
+        vert.texcoord = t0 + a.x * (t1 - t0) + a.y * (t2 - t0);
+        return vert;
+    }
+
+    // geometry/trimesh.cuh:74-80
+    Vertex SampleVertex(V2 rand) const {
+        uint32_t prim = std::min(f2u(rand.x * num_triangles), num_triangles - 1);
+        float u_sqrt = std::sqrt(rand.x * num_triangles - prim);
+        float u = 1.0f - u_sqrt;
+        float v = (1.0f - rand.y) * u_sqrt;
+        return GetVertex(prim, V2{u, v});
+    }
+};
+
+struct HitInfo {                               // accel.cuh:7-13
+    uint32_t instance_id = 0, primitive_id = 0;
+    V2 attribs{0, 0};
+    const M4 *transform = nullptr, *transform_inv = nullptr;
+};
+
+constexpr int kStackCap = 256;   // the reference's stack[32] is UB beyond 32; counted, not reproduced
+
+// accel.cuh:68-90
+bool BottomIntersect(const Mesh &m, Ray &ray, HitInfo &hit, Counters &c) {
+    uint32_t stack[kStackCap];
+    stack[0] = 0;
+    uint32_t sp = 1;
+    bool intersected = false;
+    while (sp > 0) {
+        uint32_t u = stack[--sp];
+        c.box_tests++;
+        if (BboxIntersect(m.bboxes[u].pmin, m.bboxes[u].pmax, ray)) {
+            if (m.nodes[u].rc == ~0u) {
+                float t;
+                c.tri_tests++;
+                if (m.Intersect(ray, m.nodes[u].lc_or_id, t, hit.attribs)) {
+                    ray.tmax = t;
+                    hit.primitive_id = m.nodes[u].lc_or_id;
+                    intersected = true;
+                }
+            } else {
+                stack[sp++] = m.nodes[u].lc_or_id;
+                stack[sp++] = m.nodes[u].rc;
+                if (sp > c.max_stack) c.max_stack = sp;
+            }
+        }
+    }
+    return intersected;
+}
+
+// accel.cuh:92-112
+bool BottomOcclude(const Mesh &m, const Ray &ray, Counters &c) {
+    uint32_t stack[kStackCap];
+    stack[0] = 0;
+    uint32_t sp = 1;
+    while (sp > 0) {
+        uint32_t u = stack[--sp];
+        c.box_tests++;
+        if (BboxIntersect(m.bboxes[u].pmin, m.bboxes[u].pmax, ray)) {
+            if (m.nodes[u].rc == ~0u) {
+                float t; V2 a;
+                c.tri_tests++;
+                if (m.Intersect(ray, m.nodes[u].lc_or_id, t, a)) return true;
+            } else {
+                stack[sp++] = m.nodes[u].lc_or_id;
+                stack[sp++] = m.nodes[u].rc;
+                if (sp > c.max_stack) c.max_stack = sp;
+            }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ sampler (sampler/random.cuh)
+inline uint32_t RandInitTea(uint32_t x, uint32_t y) {      // :9-19
+    uint32_t v0 = x, v1 = y, s0 = 0;
+    for (uint32_t n = 0; n < 16; n++) {
+        s0 += 0x9e3779b9;
+        v0 += ((v1 << 4) + 0xa341316c) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4);
+        v1 += ((v0 << 4) + 0xad90777d) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761e);
+    }
+    return v0;
+}
+inline uint32_t RandPcg(uint32_t &state) {                 // :21-26
+    uint32_t prev = state;
+    state = state * 747796405u + 2891336453u;
+    uint32_t word = ((prev >> ((prev >> 28u) + 4u)) ^ prev) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+struct Sampler {
+    uint32_t state;
+    float Next1D() { uint32_t rnd = RandPcg(state); return rnd / 4294967296.0f; }      // :38-41
+    V2 Next2D() { float a = Next1D(); float b = Next1D(); return {a, b}; }             // :43-45, left to right
+};
+
+// ------------------------------------------------------------------ frame (basic/frame.cuh)
+struct Frame {
+    V3 x, y, z;
+    explicit Frame(V3 normal) {                                                        // :13-20
+        z = normal;
+        float sign = normal.z > 0.0f ? 1.0f : -1.0f;
+        float a = -1.0f / (sign + normal.z);
+        float b = normal.x * normal.y * a;
+        x = {1.0f + sign * normal.x * normal.x * a, sign * b, -sign * normal.x};
+        y = {b, sign + normal.y * normal.y * a, -normal.y};
+    }
+    Frame(V3 x_, V3 y_, V3 z_) : x(x_), y(y_), z(z_) {}
+    // origin is always 0 and w = 0 at every call site: pp = p - origin * w = p - 0
+    V3 ToLocal(V3 p) const { V3 pp = p - V3{0, 0, 0} * 0.0f; return {dot(x, pp), dot(y, pp), dot(z, pp)}; }   // :25-28
+    V3 ToWorld(V3 p) const { return x * p.x + y * p.y + z * p.z + 0.0f * V3{0, 0, 0}; }                      // :30-32
+};
+
+// geometry/common.cuh:15-20
+inline void VertexTransformPdf(Vertex &v, const M4 &transform) {
+    Frame f(v.normal);
+    V3 t = mul3(transform, f.x);
+    V3 b = mul3(transform, f.y);
+    v.pdf /= length(cross(t, b));
+}
+
+// ------------------------------------------------------------------ BSDFs (bsdf/*.cuh)
+enum BsdfType { eLambert = 0, ePhong = 1, eBlinnPhong = 2, eMicrofacet = 3, eGlass = 4 };   // bsdf/bsdf.cuh:14-20
+enum LobeType { lNone = 0, lDiffuse = 1, lGlossy = 2, lSpecular = 3 };                      // bsdf/common.cuh:8-13
+enum LobeDir { dNone = 0, dReflection = 1, dTransmission = 2 };
+
+struct BsdfSample { V3 wi{0, 0, 0}; float pdf = 0; V3 weight{0, 0, 0}; int lobe_type = lNone; int lobe_dir = dNone; };
+
+// bsdf/common.cuh:28-36
+inline V3 CosineHemisphereSample(V2 rand) {
+    float phi = rand.x * k2Pi;
+    float sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+    float sin_theta = std::sqrt(rand.y), cos_theta = std::sqrt(1.0f - rand.y);
+    return {sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
+}
+inline V3 Reflect(V3 i, V3 n) { return 2.0f * dot(i, n) * n - i; }                     // :38-40
+inline V3 Refract(V3 i, V3 n, float ior) {                                             // :41-51
+    float cos_i = dot(i, n);
+    float eta = cos_i >= 0.0f ? 1.0f / ior : ior;
+    float cos_t_sqr = 1.0f - (1.0f - cos_i * cos_i) * eta * eta;
+    if (cos_t_sqr < 0.0f) return {0, 0, 0};
+    float cos_t = std::sqrt(cos_t_sqr);
+    float n_scale = eta * std::fabs(cos_i) - cos_t;
+    return (cos_i >= 0.0f ? n_scale : -n_scale) * n - eta * i;
+}
+inline V3 ReflectHalf(V3 i, V3 o) { V3 h = normalize(i + o); return h.z >= 0.0f ? h : -h; }   // :53-56
+inline V3 RefractHalf(V3 i, V3 o, float ior) {                                                // :57-61
+    float eta = i.z >= 0.0f ? 1.0f / ior : ior;
+    V3 h = normalize(eta * i + o);
+    return h.z >= 0.0f ? h : -h;
+}
+inline float Pow2(float x) { return x * x; }
+inline float Fresnel(float ior, V3 i, V3 n) {                                          // :71-84
+    float eta = dot(i, n) < 0.0f ? ior : 1.0f / ior;
+    V3 refract = Refract(i, n, ior);
+    if (refract != V3{0, 0, 0}) {
+        float idotn = std::fabs(dot(i, n));
+        float tdotn = std::fabs(dot(refract, n));
+        float rs = Pow2((idotn - eta * tdotn) / (idotn + eta * tdotn));
+        float rp = Pow2((tdotn - eta * idotn) / (tdotn + eta * idotn));
+        return 0.5f * (rs + rp);
+    }
+    return 1.0f;
+}
+
+struct Bsdf {
+    int type = eLambert;
+    V3 emission{0, 0, 0};
+    // union of the five parameter blocks (bsdf/bsdf.cuh:21-22)
+    V3 diffuse{0, 0, 0};       // Lambert.color / Phong.diffuse / BlinnPhong.diffuse / Microfacet.diffuse / Glass.reflectance
+    V3 specular{0, 0, 0};      // Phong/BlinnPhong/Microfacet.specular / Glass.transmittance
+    V3 transmittance{0, 0, 0}; // Microfacet.transmittance
+    float shininess = 0, s_norm = 0, ior = 0, roughness = 0, opacity = 0;
+
+    bool IsDelta() const { return type == eGlass; }
+
+    // ---- Lambert (bsdf/lambert.cuh:12-24)
+    BsdfSample LambertSample(V3 wo, float, V2 rand2) const {
+        V3 wi = CosineHemisphereSample(rand2);
+        wi.z = std::copysign(wi.z, wo.z);
+        BsdfSample s; s.wi = wi; s.pdf = std::fabs(wi.z) * kInvPi; s.weight = diffuse; s.lobe_type = lDiffuse; s.lobe_dir = dReflection;
+        return s;
+    }
+    float LambertPdf(V3 wo, V3 wi) const { return wo.z * wi.z >= 0.0f ? std::fabs(wi.z) * kInvPi : 1.0f; }
+    V3 LambertEval(V3 wo, V3 wi) const { return wo.z * wi.z >= 0.0f ? diffuse * std::fabs(wi.z) * kInvPi : V3{0, 0, 0}; }
+
+    // ---- Blinn-Phong (bsdf/blinn_phong.cuh:15-75)
+    BsdfSample BlinnSample(V3 wo, float rand1, V2 rand2) const {
+        float diffuse_weight = Luminance(diffuse), specular_weight = Luminance(specular);
+        float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
+        float specular_pdf = 1.0f - diffuse_pdf;
+        BsdfSample samp;
+        float d = 0.0f, s = 0.0f;
+        V3 h{0, 0, 0};
+        if (rand1 < diffuse_pdf) {
+            samp.wi = CosineHemisphereSample(rand2);
+            samp.wi.z = std::copysign(samp.wi.z, wo.z);
+            samp.lobe_type = lDiffuse; samp.lobe_dir = dReflection;
+            d = std::fabs(samp.wi.z) * kInvPi;
+            h = ReflectHalf(samp.wi, wo);
+            s = std::pow(h.z, shininess);
+        } else {
+            float phi = rand2.x * k2Pi;
+            float sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+            float cos_theta = std::pow(1.0f - rand2.y, 1.0f / (2.0f + shininess));
+            float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+            h = {sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
+            samp.wi = Reflect(wo, h);
+            samp.lobe_type = lGlossy; samp.lobe_dir = dReflection;
+            s = std::pow(h.z, shininess);
+            d = std::fabs(samp.wi.z) * kInvPi;
+        }
+        float half_pdf = s * (2.0f + shininess) * kInv2Pi;
+        samp.pdf = diffuse_pdf * d + specular_pdf * half_pdf / (4.0f * std::fabs(dot(samp.wi, h)));
+        samp.weight = (diffuse * d + specular * s * s_norm) / samp.pdf;
+        return samp;
+    }
+    float BlinnPdf(V3 wo, V3 wi) const {
+        if (wo.z * wi.z <= 0.0f) return 1.0f;
+        float diffuse_weight = Luminance(diffuse), specular_weight = Luminance(specular);
+        float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
+        float specular_pdf = 1.0f - diffuse_pdf;
+        V3 h = ReflectHalf(wi, wo);
+        float half_pdf = std::pow(h.z, shininess) * (2.0f + shininess) * kInv2Pi;
+        return diffuse_pdf * std::fabs(wi.z) * kInvPi + specular_pdf * half_pdf / (4.0f * std::fabs(dot(wi, h)));
+    }
+    V3 BlinnEval(V3 wo, V3 wi) const {
+        if (wo.z * wi.z <= 0.0f) return {0, 0, 0};
+        V3 h = ReflectHalf(wi, wo);
+        V3 d = diffuse * std::fabs(wi.z) * kInvPi;
+        V3 s = specular * std::pow(h.z, shininess) * s_norm;
+        return d + s;
+    }
+
+    // ---- Phong (bsdf/phong.cuh:16-71)
+    float PhongPdf(V3 wo, V3 wi) const {
+        if (wo.z * wi.z <= 0.0f) return 1.0f;
+        float diffuse_weight = Luminance(diffuse), specular_weight = Luminance(specular);
+        float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
+        float specular_pdf = 1.0f - diffuse_pdf;
+        V3 r{-wo.x, -wo.y, wo.z};
+        return diffuse_pdf * std::fabs(wi.z) * kInvPi + specular_pdf * std::pow(dot(r, wi), shininess) * s_norm;
+    }
+    V3 PhongEval(V3 wo, V3 wi) const {
+        if (wo.z * wi.z <= 0.0f) return {0, 0, 0};
+        V3 r{-wo.x, -wo.y, wo.z};
+        V3 d = diffuse * std::fabs(wi.z) * kInvPi;
+        V3 s = specular * std::pow(dot(r, wi), shininess) * s_norm;
+        return d + s;
+    }
+    BsdfSample PhongSample(V3 wo, float rand1, V2 rand2) const {
+        float diffuse_weight = Luminance(diffuse), specular_weight = Luminance(specular);
+        float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
+        BsdfSample samp;
+        if (rand1 < diffuse_pdf) {
+            samp.wi = CosineHemisphereSample(rand2);
+            samp.wi.z = std::copysign(samp.wi.z, wo.z);
+            samp.lobe_type = lDiffuse; samp.lobe_dir = dReflection;
+        } else {
+            float phi = rand2.x * k2Pi;
+            float sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+            float cos_theta = std::pow(1.0f - rand2.y, 1.0f / (1.0f + shininess));
+            float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+            V3 wi{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
+            Frame frame(V3{-wo.x, -wo.y, wo.z});
+            samp.wi = frame.ToWorld(wi);
+            if (samp.wi.z * wo.x <= 0.0f) { samp.pdf = 0.0f; return samp; }   // phong.cuh:37 (wo.x, as written)
+            samp.lobe_type = lGlossy; samp.lobe_dir = dReflection;
+        }
+        samp.pdf = PhongPdf(wo, samp.wi);
+        samp.weight = PhongEval(wo, samp.wi) / samp.pdf;
+        return samp;
+    }
+
+    // ---- Microfacet (bsdf/microfacet.cuh:9-138)
+    static float GgxNdf(float ndoth, float a2) { return a2 * kInvPi / Pow2(ndoth * ndoth * (a2 - 1.0f) + 1.0f); }
+    static float SmithVis(float ndotv, float ndotl, float a2) {
+        float v = ndotl * std::sqrt(a2 + (1.0f - a2) * ndotv * ndotv);
+        float l = ndotv * std::sqrt(a2 + (1.0f - a2) * ndotl * ndotl);
+        return 0.5f / (v + l);
+    }
+    void MicroWeights(V3 wo, float &sw, float &dw, float &tw) const {
+        float fr_macro = Fresnel(ior, wo, V3{0, 0, 1});
+        sw = Luminance(specular) * fr_macro;
+        dw = Luminance(diffuse) * (1.0f - fr_macro) * opacity;
+        tw = Luminance(transmittance) * (1.0f - fr_macro) * (1.0f - opacity);
+        float inv = 1.0f / (sw + dw + tw);
+        sw *= inv; dw *= inv; tw *= inv;
+    }
+    float MicroPdf(V3 wo, V3 wi) const {
+        float sw, dw, tw;
+        MicroWeights(wo, sw, dw, tw);
+        float a2 = roughness * roughness;
+        if (wo.z * wi.z <= 0.0f) {
+            V3 h = RefractHalf(wi, wo, ior);
+            float ndf = GgxNdf(h.z, a2);
+            float eta = wo.z >= 0.0f ? 1.0f / ior : ior;
+            float denom = Pow2(eta * dot(wo, h) + dot(wi, h));
+            float num = std::fabs(dot(wi, h));
+            return tw * ndf * num / denom;
+        }
+        V3 h = ReflectHalf(wi, wo);
+        float ndf = GgxNdf(h.z, a2);
+        float d = std::fabs(wi.z) * kInvPi;
+        float s = ndf / (4.0f * std::fabs(dot(wi, h)));
+        return dw * d + sw * s;
+    }
+    V3 MicroEval(V3 wo, V3 wi) const {
+        if (wo.z * wi.z <= 0.0f) {
+            V3 h = RefractHalf(wi, wo, ior);
+            float fr = Fresnel(ior, wo, h);
+            float ft = 1.0f - fr;
+            float eta = wo.z >= 0.0f ? 1.0f / ior : ior;
+            float a2 = roughness * roughness;
+            float ndf = GgxNdf(h.z, a2);
+            float vis = SmithVis(std::fabs(wo.z), std::fabs(wi.z), a2);
+            float denom = Pow2(eta * dot(wo, h) + dot(wi, h));
+            float num = 4.0f * std::fabs(dot(wo, h)) * std::fabs(dot(wi, h)) * eta * eta;
+            return transmittance * ft * (1.0f - opacity) * ndf * vis * num / denom * std::fabs(wi.z);
+        }
+        V3 h = ReflectHalf(wi, wo);
+        float fr = Fresnel(ior, wo, h);
+        float ft = 1.0f - fr;
+        float a2 = roughness * roughness;
+        float ndf = GgxNdf(h.z, a2);
+        float vis = SmithVis(std::fabs(wo.z), std::fabs(wi.z), a2);
+        V3 s = specular * fr * ndf * vis * std::fabs(wi.z);
+        V3 d = diffuse * ft * opacity * std::fabs(wi.z) * kInvPi;
+        return d + s;
+    }
+    BsdfSample MicroSample(V3 wo, float rand1, V2 rand2) const {
+        float sw, dw, tw;
+        MicroWeights(wo, sw, dw, tw);
+        BsdfSample samp;
+        if (rand1 < dw) {
+            samp.wi = CosineHemisphereSample(rand2);
+            samp.lobe_type = lDiffuse; samp.lobe_dir = dReflection;
+        } else {
+            float a2 = roughness * roughness;
+            float phi = rand2.x * k2Pi;
+            float sin_phi = std::sin(phi), cos_phi = std::cos(phi);
+            float cos_theta2 = (1.0f - rand2.y) / (1.0f - rand2.y * (1.0f - a2));
+            float cos_theta = std::sqrt(cos_theta2);
+            float sin_theta = std::sqrt(1.0f - cos_theta2);
+            V3 h{sin_theta * cos_phi, sin_theta * sin_phi, cos_theta};
+            if (rand1 < dw + sw) {
+                samp.wi = Reflect(wo, h);
+                samp.lobe_type = lGlossy; samp.lobe_dir = dReflection;
+            } else {
+                samp.wi = Refract(wo, h, ior);
+                if (samp.wi == V3{0, 0, 0}) { samp.pdf = 0.0f; samp.lobe_type = lNone; samp.lobe_dir = dNone; return samp; }
+                samp.lobe_type = lGlossy; samp.lobe_dir = dTransmission;
+            }
+        }
+        samp.pdf = MicroPdf(wo, samp.wi);
+        samp.weight = MicroEval(wo, samp.wi) / samp.pdf;
+        return samp;
+    }
+
+    // ---- Glass (bsdf/glass.cuh:14-63); reflectance = `diffuse`, transmittance = `specular` slot
+    void GlassPdfs(V3 wo, float &fr, float &ft, float &reflect_pdf, float &transmit_pdf) const {
+        fr = Fresnel(ior, wo, V3{0, 0, 1});
+        ft = 1.0f - fr;
+        float reflect_weight = fr * Luminance(diffuse);
+        float transmit_weight = ft * Luminance(specular);
+        reflect_pdf = reflect_weight / (reflect_weight + transmit_weight);
+        transmit_pdf = 1.0f - reflect_pdf;
+    }
+    BsdfSample GlassSample(V3 wo, float rand1, V2) const {
+        float fr, ft, reflect_pdf, transmit_pdf;
+        GlassPdfs(wo, fr, ft, reflect_pdf, transmit_pdf);
+        BsdfSample samp;
+        if (rand1 < reflect_pdf) {
+            samp.wi = Reflect(wo, V3{0, 0, 1});
+            samp.pdf = reflect_pdf;
+            samp.weight = fr * diffuse / reflect_pdf;
+            samp.lobe_type = lSpecular; samp.lobe_dir = dReflection;
+        } else {
+            samp.wi = Refract(wo, V3{0, 0, 1}, ior);
+            if (samp.wi == V3{0, 0, 0}) {
+                samp.pdf = 0.0f;
+            } else {
+                float eta = wo.z >= 0.0f ? 1.0f / ior : ior;
+                samp.pdf = transmit_pdf;
+                samp.weight = eta * eta * ft * specular / transmit_pdf;
+                samp.lobe_type = lSpecular; samp.lobe_dir = dTransmission;
+            }
+        }
+        return samp;
+    }
+    float GlassPdf(V3 wo, V3 wi) const {
+        float fr, ft, rp, tp;
+        GlassPdfs(wo, fr, ft, rp, tp);
+        return wo.z * wi.z >= 0.0f ? rp : tp;
+    }
+    V3 GlassEval(V3 wo, V3 wi) const {
+        float fr = Fresnel(ior, wo, V3{0, 0, 1});
+        float ft = 1.0f - fr;
+        if (wo.z * wi.z <= 0.0f) {
+            float eta = wo.z >= 0.0f ? 1.0f / ior : ior;
+            return eta * eta * ft * specular;
+        }
+        return fr * diffuse;
+    }
+
+    // bsdf/bsdf.cuh:39-82
+    BsdfSample Sample(V3 wo, float r1, V2 r2) const {
+        switch (type) {
+            case eLambert: return LambertSample(wo, r1, r2);
+            case ePhong: return PhongSample(wo, r1, r2);
+            case eBlinnPhong: return BlinnSample(wo, r1, r2);
+            case eMicrofacet: return MicroSample(wo, r1, r2);
+            default: return GlassSample(wo, r1, r2);
+        }
+    }
+    float Pdf(V3 wo, V3 wi) const {
+        switch (type) {
+            case eLambert: return LambertPdf(wo, wi);
+            case ePhong: return PhongPdf(wo, wi);
+            case eBlinnPhong: return BlinnPdf(wo, wi);
+            case eMicrofacet: return MicroPdf(wo, wi);
+            default: return GlassPdf(wo, wi);
+        }
+    }
+    V3 Eval(V3 wo, V3 wi) const {
+        switch (type) {
+            case eLambert: return LambertEval(wo, wi);
+            case ePhong: return PhongEval(wo, wi);
+            case eBlinnPhong: return BlinnEval(wo, wi);
+            case eMicrofacet: return MicroEval(wo, wi);
+            default: return GlassEval(wo, wi);
+        }
+    }
+};
+
+// ------------------------------------------------------------------ material (material/mtl.cuh, src/scene/material.hpp)
+struct Material {
+    V3 emission{0, 0, 0}, diffuse{0.5f, 0.5f, 0.5f}, specular{0.5f, 0.5f, 0.5f}, transmittance{0, 0, 0};
+    float shininess = 1.0f, ior = 1.5f, opacity = 1.0f;
+    int bsdf_type = eBlinnPhong;
+
+    bool IsEmissive() const { return dot(emission, emission) > 0.0f; }   // src/scene/material.cpp:57-59
+
+    // material/material.cuh:15-27 + material/mtl.cuh:16-66 (constant values only, no textures)
+    Bsdf GetBsdf() const {
+        Bsdf b;
+        if (bsdf_type != eMicrofacet && opacity == 0.0f) {
+            b.type = eGlass;
+            b.specular = transmittance;     // Glass.transmittance
+            b.diffuse = transmittance;      // Glass.reflectance := transmittance (mtl.cuh:22)
+            b.ior = ior;
+        } else {
+            b.type = bsdf_type;
+            switch (bsdf_type) {
+                case eLambert: b.diffuse = diffuse; break;
+                case ePhong:
+                    b.diffuse = diffuse; b.specular = specular;
+                    b.diffuse = b.diffuse * (1.0f - std::fmax(b.specular.x, std::fmax(b.specular.y, b.specular.z)));
+                    b.shininess = shininess;
+                    b.s_norm = (shininess + 1) * kInv2Pi;
+                    break;
+                case eBlinnPhong:
+                    b.diffuse = diffuse; b.specular = specular;
+                    b.diffuse = b.diffuse * (1.0f - std::fmax(b.specular.x, std::fmax(b.specular.y, b.specular.z)));
+                    b.shininess = shininess;
+                    b.s_norm = (shininess + 2) / (4 * kPi * (2 - std::pow(2.0f, -shininess / 2)));
+                    break;
+                case eMicrofacet:
+                    b.diffuse = diffuse; b.specular = specular; b.transmittance = transmittance;
+                    b.roughness = std::sqrt(2.0f / (2.0f + shininess));
+                    b.ior = ior; b.opacity = opacity;
+                    break;
+                default: break;
+            }
+        }
+        b.emission = emission;
+        return b;
+    }
+};
+
+// ------------------------------------------------------------------ scene tables
+struct Instance {
+    int mesh;
+    M4 transform, transform_inv, transform_it;
+    Material material;
+    int light = -1;      // index into Scene::lights, -1 when not emissive
+};
+
+struct PinholeCamera { V3 pos, frame_x, frame_y, frame_z, x_dir, y_dir; };   // camera/pinhole.cuh:8-14
+
+struct Scene {
+    std::vector<Mesh> meshes;
+    std::vector<Instance> instances;
+    std::vector<Node> top_nodes;
+    std::vector<Bbox> top_bboxes;
+    std::vector<uint64_t> top_keys;
+    std::vector<int> lights;     // instance index per light (pathtracer.cpp:187-200)
+    PinholeCamera camera{};
+    bool has_camera = false;
+    bool built = false;
+};
+
+// accel.cuh:124-150
+bool TopIntersect(const Scene &sc, Ray &ray, HitInfo &hit, Counters &c) {
+    c.rays++;
+    uint32_t stack[kStackCap];
+    stack[0] = 0;
+    uint32_t sp = 1;
+    bool intersected = false;
+    while (sp > 0) {
+        uint32_t u = stack[--sp];
+        c.box_tests++;
+        if (BboxIntersect(sc.top_bboxes[u].pmin, sc.top_bboxes[u].pmax, ray)) {
+            if (sc.top_nodes[u].rc == ~0u) {
+                uint32_t inst_id = sc.top_nodes[u].lc_or_id;
+                const Instance &inst = sc.instances[inst_id];
+                Ray local_ray = TransformRay(ray, inst.transform_inv);
+                if (BottomIntersect(sc.meshes[inst.mesh], local_ray, hit, c)) {
+                    ray.tmax = local_ray.tmax;
+                    hit.instance_id = inst_id;
+                    hit.transform = &inst.transform;
+                    hit.transform_inv = &inst.transform_inv;
+                    intersected = true;
+                }
+            } else {
+                stack[sp++] = sc.top_nodes[u].lc_or_id;
+                stack[sp++] = sc.top_nodes[u].rc;
+                if (sp > c.max_stack) c.max_stack = sp;
+            }
+        }
+    }
+    return intersected;
+}
+
+// accel.cuh:152-173
+bool TopOcclude(const Scene &sc, const Ray &ray, Counters &c) {
+    c.rays++;
+    uint32_t stack[kStackCap];
+    stack[0] = 0;
+    uint32_t sp = 1;
+    while (sp > 0) {
+        uint32_t u = stack[--sp];
+        c.box_tests++;
+        if (BboxIntersect(sc.top_bboxes[u].pmin, sc.top_bboxes[u].pmax, ray)) {
+            if (sc.top_nodes[u].rc == ~0u) {
+                const Instance &inst = sc.instances[sc.top_nodes[u].lc_or_id];
+                Ray local_ray = TransformRay(ray, inst.transform_inv);
+                if (BottomOcclude(sc.meshes[inst.mesh], local_ray, c)) return true;
+            } else {
+                stack[sp++] = sc.top_nodes[u].lc_or_id;
+                stack[sp++] = sc.top_nodes[u].rc;
+                if (sp > c.max_stack) c.max_stack = sp;
+            }
+        }
+    }
+    return false;
+}
+
+struct ShadingSurface { Vertex vertex; Bsdf bsdf; };
+
+// scene/instance.cuh:19-26
+ShadingSurface GetShadingSurface(const Scene &sc, const HitInfo &hit) {
+    const Instance &inst = sc.instances[hit.instance_id];
+    M4 transform_it = transpose(*hit.transform_inv);
+    Vertex v = sc.meshes[inst.mesh].GetVertex(hit.primitive_id, hit.attribs);
+    VertexTransformPdf(v, *hit.transform);
+    v.position = xyz(mul(*hit.transform, V4{v.position.x, v.position.y, v.position.z, 1.0f}));
+    v.normal = xyz(normalize4(mul(transform_it, V4{v.normal.x, v.normal.y, v.normal.z, 0.0f})));   // vec4 normalize, as written
+    ShadingSurface s;
+    s.vertex = v;
+    s.bsdf = inst.material.GetBsdf();
+    return s;
+}
+
+struct LightSample { V3 dir{0, 0, 0}; float pdf = 0; V3 weight{0, 0, 0}; float dist = 0; };   // light/common.cuh:7-12
+
+// geometry/geometry.cuh:27-39 + light/geometry.cuh:17-30
+LightSample GeometryLightSample(const Scene &sc, const Instance &inst, V3 pos, V2 rand) {
+    Vertex vert = sc.meshes[inst.mesh].SampleVertex(rand);
+    VertexTransformPdf(vert, inst.transform);
+    vert.position = xyz(mul(inst.transform, V4{vert.position.x, vert.position.y, vert.position.z, 1.0f}));
+    vert.normal = xyz(normalize4(mul(inst.transform_it, V4{vert.normal.x, vert.normal.y, vert.normal.z, 0.0f})));
+    V3 vec = vert.position - pos;
+    float dist_sqr = dot(vec, vec);
+    float dist = std::sqrt(dist_sqr);
+    V3 dir = vec / dist;
+    LightSample samp;
+    samp.dir = dir;
+    samp.dist = dist;
+    float cos_theta = dot(-dir, vert.normal);
+    samp.pdf = cos_theta > 0.0f ? vert.pdf * dist_sqr / cos_theta : 0.0f;
+    samp.weight = inst.material.emission / samp.pdf;
+    return samp;
+}
+
+// integrator/common.cuh:9-25
+inline float PowerHeuristic(float p0, float p1) { p0 *= p0; p1 *= p1; return p0 / (p0 + p1); }
+inline float PathToSolidAngleJacobian(V3 p_prev, V3 p, V3 n) {
+    V3 vec = p_prev - p;
+    float dist_sqr = dot(vec, vec);
+    V3 dir = vec * inversesqrt(dist_sqr);
+    float cos_theta = dot(n, dir);
+    return cos_theta > 0.0f ? dist_sqr / cos_theta : 0.0f;
+}
+
+// integrator/path.cu:9-83
+V3 Trace(const Scene &sc, Ray ray, Sampler &sampler, uint32_t max_depth, int channel, Counters &c) {
+    HitInfo hit;
+    if (!TopIntersect(sc, ray, hit, c)) return {0, 0, 0};
+    ShadingSurface surface = GetShadingSurface(sc, hit);
+    if (channel == 1) return surface.vertex.normal * 0.5f + V3{0.5f, 0.5f, 0.5f};
+    V3 color = surface.bsdf.emission;
+    if (color != V3{0, 0, 0}) return color;
+    V3 throughput{1, 1, 1};
+    uint32_t num_lights = (uint32_t)sc.lights.size();
+    float light_pick_pdf = num_lights != 0 ? 1.0f / num_lights : 0.0f;      // pathtracer.cpp:47
+    for (uint32_t depth = 0; depth < max_depth; depth++) {
+        Frame frame(surface.vertex.normal);
+        V3 wo = frame.ToLocal(-ray.direction);
+        if (!surface.bsdf.IsDelta()) {
+            float r1 = sampler.Next1D();
+            uint32_t index = std::min(f2u(r1 * num_lights), num_lights - 1);      // light/light.cuh:39-43
+            float light_sample_pdf = light_pick_pdf;
+            const Instance &linst = sc.instances[sc.lights[index]];
+            V2 r2 = sampler.Next2D();
+            LightSample light_samp = GeometryLightSample(sc, linst, surface.vertex.position, r2);
+            light_samp.pdf *= light_sample_pdf;
+            light_samp.weight = light_samp.weight / light_sample_pdf;
+            if (light_samp.pdf > 0.0f) {
+                Ray shadow_ray(surface.vertex.position, light_samp.dir);
+                shadow_ray.tmax = light_samp.dist - kShadowRayEps;
+                if (!TopOcclude(sc, shadow_ray, c)) {
+                    V3 wi = frame.ToLocal(light_samp.dir);
+                    float mis_weight = 1.0f;
+                    {   // GeometryLight is never delta (light/geometry.cuh:15)
+                        float bsdf_pdf = surface.bsdf.Pdf(wo, wi);
+                        mis_weight = PowerHeuristic(light_samp.pdf, bsdf_pdf);
+                    }
+                    color = color + throughput * mis_weight * light_samp.weight * surface.bsdf.Eval(wo, wi);
+                }
+            }
+        }
+        float b1 = sampler.Next1D();
+        V2 b2 = sampler.Next2D();
+        BsdfSample bsdf_samp = surface.bsdf.Sample(wo, b1, b2);
+        if (bsdf_samp.pdf == 0.0f) break;
+        throughput = throughput * bsdf_samp.weight;
+        ray = Ray(surface.vertex.position, frame.ToWorld(bsdf_samp.wi));
+        if (!TopIntersect(sc, ray, hit, c)) break;
+        surface = GetShadingSurface(sc, hit);
+        if (surface.bsdf.emission != V3{0, 0, 0} && dot(ray.direction, surface.vertex.normal) < 0.0f) {
+            float mis_weight = 1.0f;
+            if (bsdf_samp.lobe_type != lSpecular) {
+                float light_pdf = surface.vertex.pdf
+                    * PathToSolidAngleJacobian(ray.origin, surface.vertex.position, surface.vertex.normal)
+                    * light_pick_pdf;
+                mis_weight = PowerHeuristic(bsdf_samp.pdf, light_pdf);
+            }
+            color = color + throughput * mis_weight * surface.bsdf.emission;
+            break;
+        }
+        float rr_prop = gmin(gmax(Luminance(throughput), 0.01f), 0.95f);    // glm::clamp
+        if (sampler.Next1D() > rr_prop) break;
+        throughput = throughput / rr_prop;
+    }
+    return color;
+}
+
+// camera/pinhole.cuh:16-22
+Ray CameraSampleRay(const PinholeCamera &cam, float aspect, V2 position_rand) {
+    V3 dir = normalize((cam.x_dir * aspect * (position_rand.x - 0.5f)) + (cam.y_dir * (position_rand.y - 0.5f)) + V3{0.0f, 0.0f, -1.0f});
+    Frame frame(cam.frame_x, cam.frame_y, cam.frame_z);
+    dir = frame.ToWorld(dir);
+    return Ray(cam.pos, dir);
+}
+
+// integrator/path.cu:85-97 : the camera ray of one pixel for sample index `spp`
+Ray PixelRay(const Scene &sc, uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t spp, Sampler &sampler, uint32_t &pixel_index) {
+    pixel_index = (H - 1 - py) * W + px;
+    sampler.state = RandInitTea(pixel_index, spp);
+    V2 subpixel = spp == 1 ? V2{0.5f, 0.5f} : sampler.Next2D();
+    V2 pr{((float)px + subpixel.x) / (float)W, ((float)py + subpixel.y) / (float)H};
+    Ray ray = CameraSampleRay(sc.camera, (float)W / (float)H, pr);
+    (void)sampler.Next2D();     // aperture sample: drawn, unused
+    return ray;
+}
+
+// integrator/path.cu:85-105 for one pixel
+void RenderPixel(const Scene &sc, float *output, uint32_t W, uint32_t H, uint32_t px, uint32_t py, uint32_t spp,
+                 uint32_t max_depth, int channel, int sum_mode, Counters &c) {
+    Sampler sampler;
+    uint32_t pixel_index;
+    Ray ray = PixelRay(sc, W, H, px, py, spp, sampler, pixel_index);
+    V3 color = Trace(sc, ray, sampler, max_depth, channel, c);
+    if (std::isnan(color.x) || std::isnan(color.y) || std::isnan(color.z) ||
+        std::isinf(color.x) || std::isinf(color.y) || std::isinf(color.z)) color = {0, 0, 0};
+    float *o = output + 4 * (size_t)pixel_index;
+    if (sum_mode) {
+        o[0] += color.x; o[1] += color.y; o[2] += color.z; o[3] += 1.0f;
+    } else {
+        float a = 1.0f / spp;                       // glm::mix(prev, new, a) = prev*(1-a) + new*a
+        o[0] = o[0] * (1.0f - a) + color.x * a;
+        o[1] = o[1] * (1.0f - a) + color.y * a;
+        o[2] = o[2] * (1.0f - a) + color.z * a;
+        o[3] = o[3] * (1.0f - a) + 1.0f * a;
+    }
+}
+
+// src/scene/bbox.cpp:18-37
+void TransformBbox(V3 pmin, V3 pmax, const M4 &mat, V3 &omin, V3 &omax) {
+    V3 p[8];
+    const float xs[2] = {pmin.x, pmax.x}, ys[2] = {pmin.y, pmax.y}, zs[2] = {pmin.z, pmax.z};
+    for (int i = 0; i < 8; i++) p[i] = xyz(mul(mat, V4{xs[i & 1], ys[(i >> 1) & 1], zs[(i >> 2) & 1], 1.0f}));
+    omin = gmin3(gmin3(gmin3(p[0], p[1]), gmin3(p[2], p[3])), gmin3(gmin3(p[4], p[5]), gmin3(p[6], p[7])));
+    omax = gmax3(gmax3(gmax3(p[0], p[1]), gmax3(p[2], p[3])), gmax3(gmax3(p[4], p[5]), gmax3(p[6], p[7])));
+}
+
+// src/scene/mesh.cpp:84-120
+void BuildMeshAccel(Mesh &m) {
+    uint32_t n = m.num_triangles;
+    m.bb_min = {FLT_MAX, FLT_MAX, FLT_MAX};
+    m.bb_max = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (const V3 &p : m.positions) { m.bb_min = gmin3(m.bb_min, p); m.bb_max = gmax3(m.bb_max, p); }   // mesh.cpp:7-12, bbox.cpp:44-47
+    m.bboxes.assign(2 * n - 1, Bbox{});
+    m.nodes.assign(2 * n - 1, Node{});
+    m.keys.assign(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        V3 p0 = m.positions[m.indices[3 * i]], p1 = m.positions[m.indices[3 * i + 1]], p2 = m.positions[m.indices[3 * i + 2]];
+        V3 lo = gmin3(p0, gmin3(p1, p2)), hi = gmax3(p0, gmax3(p1, p2));
+        m.bboxes[n - 1 + i].pmin = {lo.x, lo.y, lo.z, 1.0f};
+        m.bboxes[n - 1 + i].pmax = {hi.x, hi.y, hi.z, 1.0f};
+    }
+    Bbox merged{{m.bb_min.x, m.bb_min.y, m.bb_min.z, 1.0f}, {m.bb_max.x, m.bb_max.y, m.bb_max.z, 1.0f}};
+    BuildAccel(m.nodes.data(), m.bboxes.data(), merged, n, m.keys.data(), nullptr);
+}
+
+// src/pathtracer/pathtracer.cpp:91-166 and :168-221
+void BuildScene(Scene &sc) {
+    for (Mesh &m : sc.meshes) BuildMeshAccel(m);
+    uint32_t n = (uint32_t)sc.instances.size();
+    sc.top_bboxes.assign(2 * n - 1, Bbox{});
+    sc.top_nodes.assign(2 * n - 1, Node{});
+    sc.top_keys.assign(n, 0);
+    Bbox merged{{FLT_MAX, FLT_MAX, FLT_MAX, 1.0f}, {-FLT_MAX, -FLT_MAX, -FLT_MAX, 1.0f}};
+    for (uint32_t i = 0; i < n; i++) {
+        const Instance &inst = sc.instances[i];
+        V3 lo, hi;
+        TransformBbox(sc.meshes[inst.mesh].bb_min, sc.meshes[inst.mesh].bb_max, inst.transform, lo, hi);
+        sc.top_bboxes[n - 1 + i].pmin = {lo.x, lo.y, lo.z, 1.0f};
+        sc.top_bboxes[n - 1 + i].pmax = {hi.x, hi.y, hi.z, 1.0f};
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const Bbox &b = sc.top_bboxes[n - 1 + i];
+        merged.pmin = {gmin(merged.pmin.x, b.pmin.x), gmin(merged.pmin.y, b.pmin.y), gmin(merged.pmin.z, b.pmin.z), gmin(merged.pmin.w, b.pmin.w)};
+        merged.pmax = {gmax(merged.pmax.x, b.pmax.x), gmax(merged.pmax.y, b.pmax.y), gmax(merged.pmax.z, b.pmax.z), gmax(merged.pmax.w, b.pmax.w)};
+    }
+    BuildAccel(sc.top_nodes.data(), sc.top_bboxes.data(), merged, n, sc.top_keys.data(), nullptr);
+    sc.lights.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        sc.instances[i].light = -1;
+        if (sc.instances[i].material.IsEmissive()) { sc.instances[i].light = (int)sc.lights.size(); sc.lights.push_back((int)i); }
+    }
+    sc.built = true;
+}
+
+M4 FromColumnMajor(const float *m) {
+    M4 r;
+    memcpy(&r, m, sizeof(M4));
+    return r;
+}
+
+}  // namespace
+
+// ==================================================================== C ABI (ctypes)
+extern "C" {
+
+uint64_t orc_morton_key(const float *leaf_box8, const float *merged8, uint32_t index) {
+    Bbox b, m;
+    memcpy(&b, leaf_box8, 32);
+    memcpy(&m, merged8, 32);
+    return MortonKey(b, m, index);
+}
+
+// nodes: uint32[2*(2n-1)], bboxes: float[8*(2n-1)] with leaves pre-filled at [n-1, 2n-1); in place.
+void orc_build_accel(uint32_t *nodes, float *bboxes, const float *merged8, uint32_t n, uint64_t *keys_out, uint32_t *parents_out) {
+    Bbox m;
+    memcpy(&m, merged8, 32);
+    BuildAccel(reinterpret_cast<Node *>(nodes), reinterpret_cast<Bbox *>(bboxes), m, n, keys_out, parents_out);
+}
+
+void *orc_scene_create() { return new Scene(); }
+void orc_scene_destroy(void *h) { delete static_cast<Scene *>(h); }
+
+int orc_scene_add_mesh(void *h, const float *pos, const float *nrm, const float *uv, uint32_t nverts, const uint32_t *idx, uint32_t ntris) {
+    Scene &sc = *static_cast<Scene *>(h);
+    Mesh m;
+    m.positions.resize(nverts); m.normals.resize(nverts); m.texcoords.resize(nverts);
+    memcpy(m.positions.data(), pos, 12 * (size_t)nverts);
+    memcpy(m.normals.data(), nrm, 12 * (size_t)nverts);
+    memcpy(m.texcoords.data(), uv, 8 * (size_t)nverts);
+    m.indices.assign(idx, idx + 3 * (size_t)ntris);
+    m.num_triangles = ntris;
+    sc.meshes.push_back(std::move(m));
+    return (int)sc.meshes.size() - 1;
+}
+
+// mat16: emission[3] diffuse[3] specular[3] transmittance[3] shininess ior opacity bsdf_type(as float)
+int orc_scene_add_instance(void *h, int mesh, const float *transform_colmajor16, const float *mat16) {
+    Scene &sc = *static_cast<Scene *>(h);
+    Instance inst;
+    inst.mesh = mesh;
+    inst.transform = FromColumnMajor(transform_colmajor16);
+    inst.transform_inv = inverse(inst.transform);
+    inst.transform_it = transpose(inst.transform_inv);
+    Material &mt = inst.material;
+    mt.emission = {mat16[0], mat16[1], mat16[2]};
+    mt.diffuse = {mat16[3], mat16[4], mat16[5]};
+    mt.specular = {mat16[6], mat16[7], mat16[8]};
+    mt.transmittance = {mat16[9], mat16[10], mat16[11]};
+    mt.shininess = mat16[12]; mt.ior = mat16[13]; mt.opacity = mat16[14]; mt.bsdf_type = (int)mat16[15];
+    sc.instances.push_back(inst);
+    return (int)sc.instances.size() - 1;
+}
+
+// src/scene/camera.cpp:28-50
+void orc_scene_set_camera(void *h, const float *pos3, const float *look_at3, const float *up3, float fov) {
+    Scene &sc = *static_cast<Scene *>(h);
+    V3 pos{pos3[0], pos3[1], pos3[2]}, look_at{look_at3[0], look_at3[1], look_at3[2]}, up{up3[0], up3[1], up3[2]};
+    V3 frame_z = normalize(pos - look_at);
+    V3 frame_x = normalize(cross(up, frame_z));
+    V3 frame_y = normalize(cross(frame_z, frame_x));
+    float radians = (fov * 0.5f) * 0.01745329251994329576923690768489f;
+    float scale = std::tan(radians) * 2.0f;
+    sc.camera = {pos, frame_x, frame_y, frame_z, V3{scale, 0, 0}, V3{0, scale, 0}};
+    sc.has_camera = true;
+}
+
+void orc_scene_build(void *h) { BuildScene(*static_cast<Scene *>(h)); }
+
+uint32_t orc_scene_num_lights(void *h) { return (uint32_t)static_cast<Scene *>(h)->lights.size(); }
+
+// copy out one BLAS (mesh >= 0) or the TLAS (mesh < 0); any pointer may be null
+void orc_scene_get_accel(void *h, int mesh, uint32_t *nodes, float *bboxes, uint64_t *keys) {
+    Scene &sc = *static_cast<Scene *>(h);
+    const std::vector<Node> &n = mesh < 0 ? sc.top_nodes : sc.meshes[mesh].nodes;
+    const std::vector<Bbox> &b = mesh < 0 ? sc.top_bboxes : sc.meshes[mesh].bboxes;
+    const std::vector<uint64_t> &k = mesh < 0 ? sc.top_keys : sc.meshes[mesh].keys;
+    if (nodes) memcpy(nodes, n.data(), sizeof(Node) * n.size());
+    if (bboxes) memcpy(bboxes, b.data(), sizeof(Bbox) * b.size());
+    if (keys) memcpy(keys, k.data(), sizeof(uint64_t) * k.size());
+}
+
+// rays: float[8] each = origin.xyz, tmin, direction.xyz, tmax
+// counters6 (optional): rays, box_tests, tri_tests, max_stack
+void orc_first_hit(void *h, const float *rays, uint64_t n, uint32_t *inst_out, uint32_t *prim_out, float *t_out, float *uv_out,
+                   uint64_t *counters4, int nthreads) {
+    const Scene &sc = *static_cast<Scene *>(h);
+    if (nthreads < 1) nthreads = 1;
+    std::vector<Counters> cs(nthreads);
+    std::atomic<uint64_t> next{0};
+    auto work = [&](int tid) {
+        const uint64_t chunk = 4096;
+        for (;;) {
+            uint64_t b = next.fetch_add(chunk);
+            if (b >= n) break;
+            uint64_t e = std::min(n, b + chunk);
+            for (uint64_t i = b; i < e; i++) {
+                Ray r;
+                const float *p = rays + 8 * i;
+                r.origin = {p[0], p[1], p[2]}; r.tmin = p[3]; r.direction = {p[4], p[5], p[6]}; r.tmax = p[7];
+                HitInfo hit;
+                bool ok = TopIntersect(sc, r, hit, cs[tid]);
+                inst_out[i] = ok ? hit.instance_id : 0xffffffffu;
+                prim_out[i] = ok ? hit.primitive_id : 0xffffffffu;
+                if (t_out) t_out[i] = ok ? r.tmax : p[7];
+                if (uv_out) { uv_out[2 * i] = ok ? hit.attribs.x : 0.0f; uv_out[2 * i + 1] = ok ? hit.attribs.y : 0.0f; }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &t : th) t.join();
+    if (counters4) {
+        Counters c;
+        for (auto &x : cs) c.add(x);
+        counters4[0] = c.rays; counters4[1] = c.box_tests; counters4[2] = c.tri_tests; counters4[3] = c.max_stack;
+    }
+}
+
+void orc_occlude(void *h, const float *rays, uint64_t n, uint8_t *out) {
+    const Scene &sc = *static_cast<Scene *>(h);
+    Counters c;
+    for (uint64_t i = 0; i < n; i++) {
+        Ray r;
+        const float *p = rays + 8 * i;
+        r.origin = {p[0], p[1], p[2]}; r.tmin = p[3]; r.direction = {p[4], p[5], p[6]}; r.tmax = p[7];
+        out[i] = TopOcclude(sc, r, c) ? 1 : 0;
+    }
+}
+
+// camera rays of sample index `spp` for every pixel, in pixel_index order (row 0 = top)
+void orc_camera_rays(void *h, uint32_t W, uint32_t H, uint32_t spp, float *rays_out) {
+    const Scene &sc = *static_cast<Scene *>(h);
+    for (uint32_t py = 0; py < H; py++)
+        for (uint32_t px = 0; px < W; px++) {
+            Sampler s;
+            uint32_t pi;
+            Ray r = PixelRay(sc, W, H, px, py, spp, s, pi);
+            float *o = rays_out + 8 * (size_t)pi;
+            o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z; o[3] = r.tmin;
+            o[4] = r.direction.x; o[5] = r.direction.y; o[6] = r.direction.z; o[7] = r.tmax;
+        }
+}
+
+// Renders sample indices spp_begin .. spp_end-1 (1-based, as PathTracer::Update counts them) into
+// output (W*H*4 floats).  sum_mode = 0: running mean exactly as path.cu:102-104; 1: plain sums.
+void orc_render(void *h, float *output, uint32_t W, uint32_t H, uint32_t spp_begin, uint32_t spp_end, int max_depth, int channel,
+                int sum_mode, int nthreads, uint64_t *counters4) {
+    const Scene &sc = *static_cast<Scene *>(h);
+    if (!sc.has_camera || sc.lights.empty()) return;     // pathtracer.cpp:27-29
+    if (nthreads < 1) nthreads = 1;
+    uint32_t md = (uint32_t)max_depth;                   // pathtracer.cpp:56
+    uint32_t tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    std::vector<Counters> cs(nthreads);
+    for (uint32_t spp = spp_begin; spp < spp_end; spp++) {
+        std::atomic<uint32_t> next{0};
+        auto work = [&](int tid) {
+            for (;;) {
+                uint32_t t = next.fetch_add(1);
+                if (t >= tiles_x * tiles_y) break;
+                uint32_t tx = t % tiles_x, ty = t / tiles_x;
+                for (uint32_t y = ty * 16; y < std::min(H, ty * 16 + 16); y++)
+                    for (uint32_t x = tx * 16; x < std::min(W, tx * 16 + 16); x++)
+                        RenderPixel(sc, output, W, H, x, y, spp, md, channel, sum_mode, cs[tid]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    if (counters4) {
+        Counters c;
+        for (auto &x : cs) c.add(x);
+        counters4[0] = c.rays; counters4[1] = c.box_tests; counters4[2] = c.tri_tests; counters4[3] = c.max_stack;
+    }
+}
+
+// ---- unit-level entry points (compared against oracle/_ref in this container)
+uint32_t orc_tea(uint32_t x, uint32_t y) { return RandInitTea(x, y); }
+void orc_next1d_seq(uint32_t state, uint32_t n, float *out) { Sampler s{state}; for (uint32_t i = 0; i < n; i++) out[i] = s.Next1D(); }
+
+int orc_bbox_intersect(const float *pmin3, const float *pmax3, const float *ray8) {
+    Ray r;
+    r.origin = {ray8[0], ray8[1], ray8[2]}; r.tmin = ray8[3]; r.direction = {ray8[4], ray8[5], ray8[6]}; r.tmax = ray8[7];
+    return BboxIntersect(V4{pmin3[0], pmin3[1], pmin3[2], 1}, V4{pmax3[0], pmax3[1], pmax3[2], 1}, r) ? 1 : 0;
+}
+
+static Bsdf BsdfFromParams(int type, const float *p14) {
+    // p14: diffuse[3] specular[3] transmittance[3] shininess s_norm ior roughness opacity
+    Bsdf b;
+    b.type = type;
+    b.diffuse = {p14[0], p14[1], p14[2]}; b.specular = {p14[3], p14[4], p14[5]}; b.transmittance = {p14[6], p14[7], p14[8]};
+    b.shininess = p14[9]; b.s_norm = p14[10]; b.ior = p14[11]; b.roughness = p14[12]; b.opacity = p14[13];
+    return b;
+}
+// out9: wi[3] pdf weight[3] lobe_type lobe_dir
+void orc_bsdf_sample(int type, const float *p14, const float *wo3, float r1, float r2x, float r2y, float *out9) {
+    Bsdf b = BsdfFromParams(type, p14);
+    BsdfSample s = b.Sample(V3{wo3[0], wo3[1], wo3[2]}, r1, V2{r2x, r2y});
+    out9[0] = s.wi.x; out9[1] = s.wi.y; out9[2] = s.wi.z; out9[3] = s.pdf;
+    out9[4] = s.weight.x; out9[5] = s.weight.y; out9[6] = s.weight.z; out9[7] = (float)s.lobe_type; out9[8] = (float)s.lobe_dir;
+}
+// out4: pdf eval[3]
+void orc_bsdf_eval(int type, const float *p14, const float *wo3, const float *wi3, float *out4) {
+    Bsdf b = BsdfFromParams(type, p14);
+    V3 wo{wo3[0], wo3[1], wo3[2]}, wi{wi3[0], wi3[1], wi3[2]};
+    out4[0] = b.Pdf(wo, wi);
+    V3 e = b.Eval(wo, wi);
+    out4[1] = e.x; out4[2] = e.y; out4[3] = e.z;
+}
+// material -> bsdf parameter block (same p14 layout + type + emission): out18 = type p14[14] emission[3]
+void orc_material_bsdf(const float *mat16, float *out18) {
+    Material mt;
+    mt.emission = {mat16[0], mat16[1], mat16[2]}; mt.diffuse = {mat16[3], mat16[4], mat16[5]};
+    mt.specular = {mat16[6], mat16[7], mat16[8]}; mt.transmittance = {mat16[9], mat16[10], mat16[11]};
+    mt.shininess = mat16[12]; mt.ior = mat16[13]; mt.opacity = mat16[14]; mt.bsdf_type = (int)mat16[15];
+    Bsdf b = mt.GetBsdf();
+    out18[0] = (float)b.type;
+    out18[1] = b.diffuse.x; out18[2] = b.diffuse.y; out18[3] = b.diffuse.z;
+    out18[4] = b.specular.x; out18[5] = b.specular.y; out18[6] = b.specular.z;
+    out18[7] = b.transmittance.x; out18[8] = b.transmittance.y; out18[9] = b.transmittance.z;
+    out18[10] = b.shininess; out18[11] = b.s_norm; out18[12] = b.ior; out18[13] = b.roughness; out18[14] = b.opacity;
+    out18[15] = b.emission.x; out18[16] = b.emission.y; out18[17] = b.emission.z;
+}
+// out9: position[3] normal[3] texcoord[2] pdf -- GetVertex (sample = 0) or SampleVertex (sample = 1), untransformed
+void orc_mesh_vertex(void *h, int mesh, int sample, uint32_t prim, float a, float b, float *out9) {
+    const Scene &sc = *static_cast<Scene *>(h);
+    Vertex v = sample ? sc.meshes[mesh].SampleVertex(V2{a, b}) : sc.meshes[mesh].GetVertex(prim, V2{a, b});
+    out9[0] = v.position.x; out9[1] = v.position.y; out9[2] = v.position.z;
+    out9[3] = v.normal.x; out9[4] = v.normal.y; out9[5] = v.normal.z;
+    out9[6] = v.texcoord.x; out9[7] = v.texcoord.y; out9[8] = v.pdf;
+}
+// out9: x[3] y[3] z[3] of Frame(normal)
+void orc_frame(const float *n3, float *out9) {
+    Frame f(V3{n3[0], n3[1], n3[2]});
+    out9[0] = f.x.x; out9[1] = f.x.y; out9[2] = f.x.z; out9[3] = f.y.x; out9[4] = f.y.y; out9[5] = f.y.z; out9[6] = f.z.x; out9[7] = f.z.y; out9[8] = f.z.z;
+}
+float orc_luminance(float r, float g, float b) { return Luminance(V3{r, g, b}); }
+
+}  // extern "C"
