@@ -67,6 +67,7 @@ _sig("cpt_tracer_set_channel", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
 _sig("cpt_tracer_update", C.c_int, [_vp])
+_sig("cpt_tracer_update_timed", C.c_int, [_vp, C.c_uint32, _vp])
 _sig("cpt_tracer_reset_accumulation", C.c_int, [_vp])
 _sig("cpt_tracer_synchronize", C.c_int, [_vp])
 _sig("cpt_tracer_current_spp", C.c_uint32, [_vp])
@@ -271,6 +272,12 @@ class Tracer:
         for _ in range(n):
             check(lib.cpt_tracer_update(self.h))
 
+    def update_timed(self, n):
+        """n Update calls; returns the device milliseconds measured on the tracer's stream."""
+        ms = C.c_float(0.0)
+        check(lib.cpt_tracer_update_timed(self.h, n, C.byref(ms)))
+        return ms.value
+
     def reset(self):
         check(lib.cpt_tracer_reset_accumulation(self.h))
 
@@ -322,9 +329,9 @@ class Tracer:
         return nodes, boxes, keys
 
     def counters(self):
-        out = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(5, dtype=np.uint64)
         check(lib.cpt_tracer_counters(self.h, out.ctypes.data))
-        return dict(rays=int(out[0]), node_visits=int(out[1]), tri_tests=int(out[2]), paths=int(out[3]))
+        return dict(rays=int(out[0]), node_visits=int(out[1]), tri_tests=int(out[2]), paths=int(out[3]), shades=int(out[4]))
 
     def reset_counters(self):
         check(lib.cpt_tracer_reset_counters(self.h))

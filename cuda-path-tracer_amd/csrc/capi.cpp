@@ -381,12 +381,18 @@ int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bb
     return rc == CPT_OK ? (int64_t)v.num_primitives : rc;
 }
 
-int cpt_tracer_counters(cpt_tracer *t, uint64_t out4[4]) {
+int cpt_tracer_update_timed(cpt_tracer *t, uint32_t count, float *elapsed_ms) {
+    TRACER_OR_FAIL(t);
+    if (!elapsed_ms) return Fail(CPT_ERR_INVALID, "cpt_tracer_update_timed: null argument");
+    return Guard([&] { *elapsed_ms = t->tracer->UpdateTimed(count); return CPT_OK; });
+}
+
+int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]) {
     TRACER_OR_FAIL(t);
     return Guard([&] {
-        unsigned long long c[4];
+        unsigned long long c[5];
         t->tracer->ReadCounters(c);
-        for (int i = 0; i < 4; i++) out4[i] = c[i];
+        for (int i = 0; i < 5; i++) out5[i] = c[i];
         return CPT_OK;
     });
 }

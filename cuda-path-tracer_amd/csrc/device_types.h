@@ -87,6 +87,7 @@ struct Counters {
     unsigned long long node_visits; // 64-byte records fetched
     unsigned long long tri_tests;   // triangle records fetched
     unsigned long long paths;       // camera paths started
+    unsigned long long shades;      // shading surfaces evaluated (vertex fetch + material read)
 };
 
 struct SceneDev {

@@ -54,6 +54,8 @@ PathTracer::PathTracer(Scene &scene, Film &film) : scene_(scene), film_(film) {}
 
 PathTracer::~PathTracer() {
     workspace_.release();
+    if (ev_begin_) (void)hipEventDestroy(ev_begin_);
+    if (ev_end_) (void)hipEventDestroy(ev_end_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -274,13 +276,25 @@ void PathTracer::Synchronize() {
     if (stream_) CPT_HIP(hipStreamSynchronize(stream_));
 }
 
-void PathTracer::ReadCounters(unsigned long long out[4]) {
+float PathTracer::UpdateTimed(uint32_t count) {
+    if (!stream_) return 0.0f;
+    if (!ev_begin_) { CPT_HIP(hipEventCreate(&ev_begin_)); CPT_HIP(hipEventCreate(&ev_end_)); }
+    CPT_HIP(hipEventRecord(ev_begin_, stream_));
+    for (uint32_t i = 0; i < count; i++) Update();
+    CPT_HIP(hipEventRecord(ev_end_, stream_));
+    CPT_HIP(hipEventSynchronize(ev_end_));
+    float ms = 0.0f;
+    CPT_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    return ms;
+}
+
+void PathTracer::ReadCounters(unsigned long long out[5]) {
     cpt::Counters c{};
     if (counters_.Size()) {
         CPT_HIP(hipMemcpyAsync(&c, counters_.GpuData(), sizeof(c), hipMemcpyDeviceToHost, stream_));
         CPT_HIP(hipStreamSynchronize(stream_));
     }
-    out[0] = c.rays; out[1] = c.node_visits; out[2] = c.tri_tests; out[3] = c.paths;
+    out[0] = c.rays; out[1] = c.node_visits; out[2] = c.tri_tests; out[3] = c.paths; out[4] = c.shades;
 }
 
 void PathTracer::ResetCounters() {

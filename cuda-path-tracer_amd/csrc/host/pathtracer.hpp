@@ -38,7 +38,9 @@ public:
     // Renders sample indices [spp_begin, spp_begin + count) (1-based) into `output` (device,
     // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
     void RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height);
-    void ReadCounters(unsigned long long out[4]);
+    void ReadCounters(unsigned long long out[5]);
+    // `count` Update() calls bracketed by events on the tracer's stream; returns device milliseconds
+    float UpdateTimed(uint32_t count);
     void ResetCounters();
 
     struct AccelView { const cpt::AccelNode *nodes; const cpt::Bbox *bboxes; const uint64_t *keys; uint32_t num_primitives; };
@@ -63,6 +65,7 @@ private:
     Scene &scene_;
     Film &film_;
     hipStream_t stream_ = nullptr;
+    hipEvent_t ev_begin_ = nullptr, ev_end_ = nullptr;
 
     std::string capture_name_;
     int max_depth_ = -1;

@@ -15,7 +15,8 @@ namespace {
 struct Surface { Vertex vertex; BsdfDev bsdf; int32_t light; };
 
 // src/kernels/scene/instance.cuh:19-26
-__device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit) {
+__device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit, LaneCounters &cnt) {
+    cnt.shades++;
     const InstanceDev &in = sc.instances[hit.inst];
     const MeshDev &m = sc.meshes[in.mesh];
     Surface s;
@@ -62,7 +63,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
     Hit hit;
     float tmax = kRayTMax;
     if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
-    Surface surface = shading_surface(sc, hit);
+    Surface surface = shading_surface(sc, hit, cnt);
     if (channel == 1) return surface.vertex.normal * 0.5f + v3(0.5f);
     V3 color = surface.bsdf.emission;
     if (!is_zero(color)) return color;
@@ -100,7 +101,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
         tmax = kRayTMax;
         if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) break;
 
-        surface = shading_surface(sc, hit);
+        surface = shading_surface(sc, hit, cnt);
         if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
             float mis_weight = 1.0f;
             if (bs.lobe != kLobeSpecular) {
@@ -121,18 +122,20 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
 
 __device__ inline void flush_counters(const SceneDev &sc, const LaneCounters &cnt, uint32_t paths, unsigned long long *block_cnt) {
     if (!sc.counters) return;
-    if (threadIdx.x < 4) block_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 5) block_cnt[threadIdx.x] = 0;
     __syncthreads();
     atomicAdd(&block_cnt[0], (unsigned long long)cnt.rays);
     atomicAdd(&block_cnt[1], (unsigned long long)cnt.nodes);
     atomicAdd(&block_cnt[2], (unsigned long long)cnt.tris);
     atomicAdd(&block_cnt[3], (unsigned long long)paths);
+    atomicAdd(&block_cnt[4], (unsigned long long)cnt.shades);
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&sc.counters->rays, block_cnt[0]);
         atomicAdd(&sc.counters->node_visits, block_cnt[1]);
         atomicAdd(&sc.counters->tri_tests, block_cnt[2]);
         atomicAdd(&sc.counters->paths, block_cnt[3]);
+        atomicAdd(&sc.counters->shades, block_cnt[4]);
     }
 }
 
@@ -147,7 +150,7 @@ __device__ inline uint32_t xcd_band_remap(uint32_t b, uint32_t nb) {
 // one workgroup = one 16x16 pixel tile, one wave = one 8x8 sub-tile
 __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParams p) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
-    __shared__ unsigned long long s_cnt[4];
+    __shared__ unsigned long long s_cnt[5];
     TraceStack st;
     st.lds = s_stack;
     LaneCounters cnt;
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
 __global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
-    __shared__ unsigned long long s_cnt[4];
+    __shared__ unsigned long long s_cnt[5];
     TraceStack st;
     st.lds = s_stack;
     LaneCounters cnt;
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const fl
 
 __global__ void __launch_bounds__(kTraceBlock) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
-    __shared__ unsigned long long s_cnt[4];
+    __shared__ unsigned long long s_cnt[5];
     TraceStack st;
     st.lds = s_stack;
     LaneCounters cnt;

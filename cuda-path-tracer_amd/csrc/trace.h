@@ -22,7 +22,7 @@ constexpr int kLdsStackEntries = 24;   // per lane, in LDS: 24 * 8 B * 256 lanes
 constexpr int kSpillEntries = 40;      // per lane, private memory, touched only by very deep trees
 constexpr int kTraceBlock = 256;
 
-struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0; };
+struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; };
 
 // Per-lane stack of (node reference, entry distance) pairs.  Entry e of lane l lives at
 // lds[e * 256 + l]: lanes of a wave always touch consecutive 8-byte slots, whatever their depths.

@@ -103,6 +103,9 @@ int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour,
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
 int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */
 int cpt_tracer_update(cpt_tracer *t);                               /* PathTracer::Update: one more sample per pixel (asynchronous) */
+/* `count` Update calls bracketed by HIP events on the tracer's own stream; elapsed_ms receives the
+ * device time of the whole batch.  Synchronises. */
+int cpt_tracer_update_timed(cpt_tracer *t, uint32_t count, float *elapsed_ms);
 int cpt_tracer_reset_accumulation(cpt_tracer *t);                   /* PathTracer::ResetAccumelation + cleared film */
 int cpt_tracer_synchronize(cpt_tracer *t);
 uint32_t cpt_tracer_current_spp(const cpt_tracer *t);
@@ -133,8 +136,8 @@ int cpt_tracer_camera_rays(cpt_tracer *t, uint32_t width, uint32_t height, uint3
  * uint32, bboxes: 8*(2n-1) floats, keys: n uint64; any of them may be NULL.  Returns n. */
 int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bboxes, uint64_t *keys);
 /* counters since the last reset: rays (closest + any hit queries), 64-byte node records
- * fetched, triangle records fetched, camera paths started */
-int cpt_tracer_counters(cpt_tracer *t, uint64_t out4[4]);
+ * fetched, triangle records fetched, camera paths started, shading surfaces evaluated */
+int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
 

@@ -1203,6 +1203,9 @@ void orc_scene_set_camera(void *h, const float *pos3, const float *look_at3, con
     sc.has_camera = true;
 }
 
+// pos frame_x frame_y frame_z x_dir y_dir (the PinholeCamera block of camera/pinhole.cuh:8-14)
+void orc_scene_get_camera(void *h, float *out18) { memcpy(out18, &static_cast<Scene *>(h)->camera, 72); }
+
 void orc_scene_build(void *h) { BuildScene(*static_cast<Scene *>(h)); }
 
 uint32_t orc_scene_num_lights(void *h) { return (uint32_t)static_cast<Scene *>(h)->lights.size(); }

@@ -46,6 +46,7 @@ def oracle():
     L.orc_scene_add_instance.argtypes = [C.c_void_p, C.c_int, f32p, f32p]
     L.orc_scene_set_camera.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_float]
     L.orc_scene_build.argtypes = [C.c_void_p]
+    L.orc_scene_get_camera.argtypes = [C.c_void_p, f32p]
     L.orc_scene_num_lights.restype = C.c_uint32
     L.orc_scene_num_lights.argtypes = [C.c_void_p]
     L.orc_scene_get_accel.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -376,8 +377,8 @@ def synthetic_scene(kind, ntris, seed=12345):
         nx = int(round((ntris / 2) ** 0.5))
         mesh = heightfield(nx, max(1, ntris // (2 * nx)), seed)
     mesh["material"] = diffuse_material()
-    cam = dict(pos=np.array([0.5, 1.2, -1.6], dtype=np.float32), look_at=np.array([0.5, 0.3, 0.5], dtype=np.float32),
-               up=np.array([0, 1, 0], dtype=np.float32), fov=40.0, width=256, height=256)
+    cam = dict(pos=np.array([0.5, 0.8, -0.5], dtype=np.float32), look_at=np.array([0.5, 0.0, 0.5], dtype=np.float32),
+               up=np.array([0, 1, 0], dtype=np.float32), fov=55.0, width=256, height=256)
     return [mesh, quad_light()], cam
 
 

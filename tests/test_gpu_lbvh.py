@@ -1,0 +1,150 @@
+"""GPU: the LBVH builder behind cpt_build_accel is bit-exact against the oracle -- sorted 64-bit
+Morton keys, node topology, parent links and every box (compared as bit patterns)."""
+import numpy as np
+import pytest
+
+from helpers import *  # noqa: F403
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_build(boxes, merged):
+    L = oracle()
+    n = len(boxes)
+    nn = 2 * n - 1
+    o_boxes = np.zeros((nn, 8), np.float32)
+    o_boxes[n - 1:] = boxes
+    o_nodes = np.zeros((nn, 2), np.uint32)
+    o_keys = np.zeros(n, np.uint64)
+    o_par = np.zeros(nn, np.uint32)
+    L.orc_build_accel(o_nodes.reshape(-1), o_boxes.reshape(-1), np.ascontiguousarray(merged), n, o_keys.ctypes.data, o_par.ctypes.data)
+    return o_nodes, o_boxes, o_keys, o_par
+
+
+def assert_same_build(cpt, boxes, merged):
+    o_nodes, o_boxes, o_keys, o_par = oracle_build(boxes, merged)
+    g_nodes, g_boxes, g_keys, g_par, _ = cpt.build_accel(boxes, merged)
+    assert np.array_equal(g_keys, o_keys), "sorted Morton keys differ"
+    assert np.array_equal(g_nodes, o_nodes), "node arrays differ"
+    assert np.array_equal(g_par[1:], o_par[1:]), "parent links differ"
+    assert np.array_equal(g_boxes.view(np.uint32), o_boxes.view(np.uint32)), "boxes differ bitwise"
+    return g_nodes, g_boxes, g_keys
+
+
+@pytest.mark.parametrize("glass", [False, True])
+def test_cornell_meshes(cpt, glass):
+    objs, _ = cornell(glass=glass)
+    for o in objs:
+        boxes, merged = boxes_of_triangles(o["positions"], o["indices"])
+        assert_same_build(cpt, boxes, merged)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 64, 65, 1000, 4096, 4097, 12289, 100000])
+def test_random_soup(cpt, n):
+    soup = random_soup(n, seed=1000 + n)
+    boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+    assert_same_build(cpt, boxes, merged)
+
+
+def test_heightfield(cpt):
+    hf = heightfield(300, 300)
+    boxes, merged = boxes_of_triangles(hf["positions"], hf["indices"])
+    assert_same_build(cpt, boxes, merged)
+
+
+def test_identical_boxes_fall_back_to_the_index_bits(cpt):
+    # equal Morton codes everywhere: order and topology are decided by the low 32 key bits
+    n = 3000
+    boxes = np.tile(np.array([[0.25, 0.25, 0.25, 1, 0.5, 0.5, 0.5, 1]], np.float32), (n, 1))
+    merged = np.array([0, 0, 0, 1, 1, 1, 1, 1], np.float32)
+    nodes, _, keys = assert_same_build(cpt, boxes, merged)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), np.arange(n, dtype=np.uint32))
+
+
+def test_flat_axes_and_signed_zeros(cpt):
+    rng = np.random.default_rng(3)
+    n = 2000
+    lo = rng.random((n, 3), dtype=np.float32) - np.float32(0.5)
+    hi = lo + rng.random((n, 3), dtype=np.float32) * np.float32(0.1)
+    lo[:, 1] = np.float32(-0.0)       # the whole set is flat in y: 0/0 -> NaN -> 1023
+    hi[:, 1] = np.float32(0.0)
+    lo[::7, 0] = np.float32(-0.0)
+    boxes = np.ones((n, 8), np.float32)
+    boxes[:, 0:3] = lo
+    boxes[:, 4:7] = hi
+    merged = np.ones(8, np.float32)
+    merged[0:3] = lo.min(axis=0)
+    merged[4:7] = hi.max(axis=0)
+    merged[1] = np.float32(-0.0)
+    assert_same_build(cpt, boxes, merged)
+
+
+def test_in_place_entry_point_matches_ex(cpt):
+    soup = random_soup(5000, seed=5)
+    boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+    n = len(boxes)
+    all_boxes = np.zeros((2 * n - 1, 8), np.float32)
+    all_boxes[n - 1:] = boxes
+    d_boxes = cpt.DeviceArray.from_host(all_boxes)
+    d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
+    cpt.check(cpt.lib.cpt_build_accel(d_nodes.ptr, d_boxes.ptr, merged, n))
+    o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
+    assert np.array_equal(d_nodes.to_host(), o_nodes)
+    assert np.array_equal(d_boxes.to_host().view(np.uint32), o_boxes.view(np.uint32))
+    assert cpt.lib.cpt_build_accel(d_nodes.ptr, d_boxes.ptr, merged, 0) == 0           # empty input is a no-op
+    assert cpt.lib.cpt_build_accel(None, d_boxes.ptr, merged, n) < 0                   # null pointer is rejected
+
+
+def check_tree_properties(nodes, boxes, keys, leaf_boxes, merged):
+    """Size-independent invariants of a finished build."""
+    n = len(keys)
+    assert np.all(keys[1:] > keys[:-1]), "keys not strictly ascending"
+    prim = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    assert np.array_equal(np.sort(prim), np.arange(n, dtype=np.uint32)), "not a permutation of the primitives"
+    assert np.array_equal(nodes[n - 1:, 0], prim) and np.all(nodes[n - 1:, 1] == 0xFFFFFFFF)
+    assert np.array_equal(boxes[n - 1:].view(np.uint32), leaf_boxes[prim].view(np.uint32)), "leaf boxes not permuted with the keys"
+    lc, rc = nodes[:n - 1, 0].astype(np.int64), nodes[:n - 1, 1].astype(np.int64)
+    kids = np.concatenate([lc, rc])
+    assert np.array_equal(np.sort(kids), np.arange(1, 2 * n - 1)), "every node except the root must have exactly one parent"
+    lo = np.minimum(boxes[lc, 0:3], boxes[rc, 0:3])
+    hi = np.maximum(boxes[lc, 4:7], boxes[rc, 4:7])
+    assert np.array_equal(boxes[:n - 1, 0:3], lo) and np.array_equal(boxes[:n - 1, 4:7], hi), "internal box != union of children"
+    assert np.array_equal(boxes[0, 0:3], leaf_boxes[:, 0:3].min(axis=0)) and np.array_equal(boxes[0, 4:7], leaf_boxes[:, 4:7].max(axis=0))
+
+
+@pytest.mark.parametrize("n,kind", [(1_000_000, "soup"), (1_000_000, "heightfield"), (10_000_000, "soup")])
+def test_full_size_builds(cpt, n, kind):
+    if kind == "soup":
+        mesh = random_soup(n, seed=12345)
+    else:
+        mesh = heightfield(int(round((n / 2) ** 0.5)), int(round((n / 2) ** 0.5)))
+    boxes, merged = boxes_of_triangles(mesh["positions"], mesh["indices"])
+    del mesh
+    g_nodes, g_boxes, g_keys, g_par, stage = cpt.build_accel(boxes, merged)
+    check_tree_properties(g_nodes, g_boxes, g_keys, boxes, merged)
+    o_nodes, o_boxes, o_keys, o_par = oracle_build(boxes, merged)
+    assert np.array_equal(g_keys, o_keys)
+    assert np.array_equal(g_nodes, o_nodes)
+    assert np.array_equal(g_par[1:], o_par[1:])
+    assert np.array_equal(g_boxes.view(np.uint32), o_boxes.view(np.uint32))
+
+
+def test_reusable_builder_is_deterministic(cpt):
+    soup = random_soup(200000, seed=77)
+    boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+    n = len(boxes)
+    d_leaf = cpt.DeviceArray.from_host(boxes)
+    d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
+    d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
+    b = cpt.lib.cpt_builder_create()
+    first = None
+    for _ in range(3):
+        ms = np.zeros(1, np.float32)
+        cpt.check(cpt.lib.cpt_builder_build(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, ms.ctypes.data, None))
+        got = (d_nodes.to_host(), d_boxes.to_host().view(np.uint32))
+        if first is None:
+            first = got
+        assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]) and ms[0] > 0
+    cpt.lib.cpt_builder_destroy(b)
+    o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
+    assert np.array_equal(first[0], o_nodes) and np.array_equal(first[1], o_boxes.view(np.uint32))

@@ -1,0 +1,136 @@
+"""GPU: the bounce loop against the oracle.  Random streams are identical on both sides and the
+ray/scene arithmetic is bit-exact, so images differ only through last-ulp differences between the
+device and host sinf/cosf/powf (a handful of paths flip a decision).  Stated tolerance: relative
+L2 error <= 1e-2 and per-channel mean within 1e-3 relative at 16 spp on a 64x64 image."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import *  # noqa: F403
+from test_capi_and_host import BINARY, parse_exr
+from test_gpu_traverse import gpu_scene
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-2
+MEAN_TOL = 1e-3
+
+
+def rel_l2(a, b):
+    return float(np.sqrt(((a - b) ** 2).sum() / (b ** 2).sum()))
+
+
+def compare(img, ref):
+    assert np.all(np.isfinite(img))
+    assert rel_l2(img[..., :3], ref[..., :3]) <= REL_L2_TOL, rel_l2(img[..., :3], ref[..., :3])
+    assert np.allclose(img[..., :3].mean(axis=(0, 1)), ref[..., :3].mean(axis=(0, 1)), rtol=MEAN_TOL, atol=1e-5)
+    assert np.array_equal(img[..., 3], ref[..., 3])
+
+
+@pytest.mark.parametrize("glass,depth,bsdf", [(False, 5, 2), (True, 8, 2), (True, -1, 2), (False, 5, 0), (False, 5, 1), (True, 5, 3)])
+def test_cornell_against_oracle(cpt, glass, depth, bsdf):
+    objs, cam = cornell(glass=glass, bsdf_type=bsdf)
+    osc = OracleScene(objs, cam)
+    d = os.path.join(SCENES, "cornell-box-glass" if glass else "cornell-box")
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), bsdf).load_json(os.path.join(d, "cornell-box.json"))
+    tr = cpt.Tracer(sc, 64, 64, max_depth=depth).build_buffers()
+    assert tr is not None and cpt.lib.cpt_tracer_num_lights(tr.h) == 1
+    tr.update(16)
+    img = tr.film()
+    ref, ocnt = osc.render(64, 64, 1, 17, depth)
+    compare(img, ref)
+    c = tr.counters()
+    assert c["paths"] == 64 * 64 * 16
+    assert abs(c["rays"] - int(ocnt[0])) <= 0.002 * int(ocnt[0])         # same paths up to a few flipped decisions
+
+
+def test_survey_statistics(cpt):
+    d = os.path.join(SCENES, "cornell-box-glass")
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+    tr = cpt.Tracer(sc, 64, 64, max_depth=5).build_buffers()
+    tr.update(16)
+    mean = tr.film()[..., :3].mean(axis=(0, 1))
+    assert np.allclose(mean, [0.195, 0.129, 0.037], rtol=0.03), mean       # observed from the reference itself
+
+
+def test_normal_channel_is_deterministic_and_exactish(cpt):
+    objs, cam = cornell(glass=False)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam, 96, 96)
+    tr.set_channel(1)
+    tr.update(1)
+    img = tr.film()
+    ref, _ = osc.render(96, 96, 1, 2, 5, channel=1)
+    assert np.allclose(img, ref, atol=1e-6)
+
+
+def test_sum_mode_and_sample_sharding(cpt):
+    """Disjoint sample sets rendered into separate sum buffers add up to the single-device render:
+    the N-GPU path with no collective, checked on one GPU."""
+    objs, cam = cornell(glass=True)
+    sc, tr = gpu_scene(cpt, objs, cam, 48, 48, max_depth=6)
+    W = H = 48
+    whole = cpt.DeviceArray((H, W, 4), np.float32); whole.zero()
+    tr.render_samples(1, 12, True, whole.ptr, W, H)
+    parts = []
+    for rank in range(3):
+        buf = cpt.DeviceArray((H, W, 4), np.float32); buf.zero()
+        tr.render_samples(1 + 4 * rank, 4, True, buf.ptr, W, H)
+        parts.append(buf)
+    tr.synchronize()
+    total = sum(p.to_host().astype(np.float64) for p in parts)
+    w = whole.to_host()
+    assert np.array_equal(w[..., 3], np.full((H, W), 12.0, np.float32))
+    assert np.allclose(total, w, rtol=1e-5, atol=1e-6)                    # fp32 summation order only
+    # running mean of the same 12 samples == sum / 12 up to rounding
+    tr.reset()
+    tr.update(12)
+    mean = tr.film()
+    assert np.allclose(mean[..., :3], w[..., :3] / 12.0, rtol=2e-5, atol=1e-6)
+    # and the oracle agrees in sum mode
+    osc = OracleScene(objs, cam)
+    ref, _ = osc.render(W, H, 1, 13, 6, sum_mode=1)
+    assert rel_l2(w[..., :3], ref[..., :3]) <= REL_L2_TOL
+
+
+def test_reset_and_no_light_behaviour(cpt):
+    objs, cam = cornell(glass=False)
+    sc, tr = gpu_scene(cpt, objs, cam, 32, 32)
+    tr.update(3)
+    a = tr.film()
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 3
+    tr.reset()
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 0
+    tr.update(3)
+    assert np.array_equal(tr.film(), a)                                    # same sample indices, same image
+    dark = [o for o in objs if o["material"][0:3].sum() == 0]
+    sc2, tr2 = gpu_scene(cpt, dark, cam, 32, 32)
+    tr2.update(2)                                                          # silently renders nothing (pathtracer.cpp:27-29)
+    assert cpt.lib.cpt_tracer_current_spp(tr2.h) == 0 and not tr2.film().any()
+
+
+def test_synthetic_scene_render(cpt):
+    objs, cam = synthetic_scene("heightfield", 20000)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=4)
+    tr.update(8)
+    ref, _ = osc.render(64, 64, 1, 9, 4)
+    compare(tr.film(), ref)
+
+
+def test_cli_renders_an_exr(cpt, tmp_path):
+    d = os.path.join(SCENES, "cornell-box")
+    cam = tmp_path / "cam.json"
+    cam.write_text('{"camera": {"pos": [6.8, 1, 0], "look_at": [0, 1, 0], "up": [0, 1, 0], "fov": 19.5, "resolution": [64, 48]}}')
+    out = tmp_path / "shot"
+    r = subprocess.run([BINARY, os.path.join(d, "cornell-box.obj"), str(cam), "--ui", "0", "--max-depth", "5", "--max-spp", "32", "-o", str(out),
+                        "--bsdf-type", "blinn-phong"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "spp 16" in r.stdout and "spp 32" in r.stdout
+    img, attrs, chans = parse_exr(str(out) + ".exr")
+    assert img.shape == (48, 64, 4) and np.all(img[..., 3] == 1.0)
+    objs, c = cornell(glass=False)
+    ref, _ = OracleScene(objs, c).render(64, 48, 1, 33, 5)
+    compare(img, ref)

@@ -1,0 +1,132 @@
+"""GPU: first-hit instance/primitive ids, hit distances and barycentrics of the packed-record
+traversal are bit-exact against the oracle (and against vectors produced by the reference's own
+traversal code) for identical rays; any-hit queries agree exactly."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import *  # noqa: F403
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5):
+    sc = cpt.Scene()
+    for o in objects:
+        sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+    sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], width, height)
+    return sc, cpt.Tracer(sc, width, height, max_depth=max_depth).build_buffers()
+
+
+def interior_rays(n, seed, lo, hi, tmax=None):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for k in range(min(n, 96)):
+        d[k, k % 3] = 0.0 if k % 4 else -0.0
+        if k % 2:
+            d[k, (k + 1) % 3] = 0.0
+        if not d[k].any():
+            d[k, 2] = 1.0
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = o
+    rays[:, 3] = 1e-4
+    rays[:, 4:7] = d
+    rays[:, 7] = np.finfo(np.float32).max if tmax is None else tmax
+    return rays
+
+
+def assert_same_hits(tr, osc, rays):
+    o_inst, o_prim, o_t, o_uv, cnt = osc.first_hit(rays)
+    g_inst, g_prim, g_t, g_uv = tr.first_hit(rays)
+    assert np.array_equal(g_inst, o_inst), f"{int((g_inst != o_inst).sum())} instance ids differ"
+    assert np.array_equal(g_prim, o_prim), f"{int((g_prim != o_prim).sum())} primitive ids differ"
+    assert np.array_equal(g_t.view(np.uint32), o_t.view(np.uint32)), "hit distances differ bitwise"
+    assert np.array_equal(g_uv, o_uv), "barycentrics differ"
+    return o_inst, cnt
+
+
+@pytest.mark.parametrize("glass", [False, True])
+def test_cornell_camera_and_interior_rays(cpt, glass):
+    objs, cam = cornell(glass=glass)
+    osc = OracleScene(objs, cam)
+    d = os.path.join(SCENES, "cornell-box-glass" if glass else "cornell-box")
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+    tr = cpt.Tracer(sc, 64, 64, max_depth=5).build_buffers()
+    for spp in (1, 2, 9):
+        rays = osc.camera_rays(512, 512, spp)
+        g_rays = tr.camera_rays(512, 512, spp)
+        assert np.array_equal(g_rays.view(np.uint32), rays.view(np.uint32)), "camera rays differ bitwise"
+        inst, _ = assert_same_hits(tr, osc, rays)
+        if spp == 1:
+            assert int((inst == 0xFFFFFFFF).sum()) == 14       # rays through edge cracks, as the reference shows
+    rays = interior_rays(200000, 5, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32))
+    assert_same_hits(tr, osc, rays)
+    # rays that start exactly on surfaces (secondary-ray situation) and short rays
+    rays[:50000, 1] = 0.0
+    rays[50000:100000, 0] = -1.0
+    rays[100000:, 7] = 0.75
+    assert_same_hits(tr, osc, rays)
+    sh = interior_rays(100000, 6, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32), tmax=0.9)
+    assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
+
+
+def test_against_reference_vectors(cpt):
+    g = np.load(os.path.join(GOLDEN, "ref_traversal.npz"))
+    for glass, tag in ((False, "box"), (True, "glass")):
+        d = os.path.join(SCENES, "cornell-box-glass" if glass else "cornell-box")
+        sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+        tr = cpt.Tracer(sc, 32, 32).build_buffers()
+        rays = np.concatenate([tr.camera_rays(96, 96, 1), tr.camera_rays(96, 96, 5), g[f"{tag}_rand_rays"]])
+        inst, prim, t, uv = tr.first_hit(rays)
+        assert np.array_equal(inst.astype(np.int64).astype(np.int16), g[f"{tag}_inst"])
+        assert np.array_equal(prim.astype(np.int64).astype(np.int16), g[f"{tag}_prim"])
+        assert np.array_equal(t.view(np.uint32), g[f"{tag}_t"].view(np.uint32))
+        assert np.array_equal(uv, g[f"{tag}_uv"])
+        sh = g[f"{tag}_rand_rays"].copy()
+        sh[:, 7] = 0.9
+        assert np.array_equal(tr.occlude(sh), g[f"{tag}_occluded_tmax0.9"])
+    assert np.array_equal(cpt.Tracer(sc, 8, 8).build_buffers().camera_rays(24, 24, 1).view(np.uint32)[:0], np.zeros((0, 8), np.uint32))
+
+
+@pytest.mark.parametrize("kind,ntris", [("soup", 200000), ("heightfield", 180000), ("soup", 1)])
+def test_synthetic_scenes(cpt, kind, ntris):
+    objs, cam = synthetic_scene(kind, ntris)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam)
+    for i in (-1, 0, 1):
+        gn, gb, gk = tr.accel(i)
+        on, ob, ok = osc.accel(i)
+        assert np.array_equal(gn, on) and np.array_equal(gk, ok) and np.array_equal(gb.view(np.uint32), ob.view(np.uint32))
+    rays = osc.camera_rays(384, 384, 3)
+    inst, cnt = assert_same_hits(tr, osc, rays)
+    if ntris > 1:
+        assert (inst != 0xFFFFFFFF).mean() > 0.05
+    rays = interior_rays(100000, 8, np.array([0, -0.2, 0], np.float32), np.array([1, 1.5, 1], np.float32))
+    assert_same_hits(tr, osc, rays)
+    sh = interior_rays(50000, 9, np.array([0, -0.2, 0], np.float32), np.array([1, 1.5, 1], np.float32), tmax=0.5)
+    assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
+
+
+def test_counters_and_edge_cases(cpt):
+    objs, cam = cornell(glass=False)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam)
+    tr.reset_counters()
+    rays = osc.camera_rays(128, 128, 1)
+    _, cnt = assert_same_hits(tr, osc, rays)
+    c = tr.counters()
+    assert c["rays"] == len(rays) == int(cnt[0])
+    assert c["tri_tests"] == int(cnt[2])                 # the same triangles are tested, in the same order
+    assert c["paths"] == 0 and c["node_visits"] > 0
+    empty = np.zeros((0, 8), np.float32)
+    inst, prim, t, uv = tr.first_hit(empty)
+    assert len(inst) == 0
+    # NaN direction and zero direction: no hit, no hang
+    bad = np.zeros((2, 8), np.float32)
+    bad[:, 3] = 1e-4
+    bad[:, 7] = 1e30
+    bad[0, 4:7] = np.nan
+    assert_same_hits(tr, osc, bad)
