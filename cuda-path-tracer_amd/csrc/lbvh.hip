@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_leaves(const uint64_t *__rest
     nodes[(n - 1) + i] = AccelNode{prim, ~0u};
 }
 
+constexpr uint32_t kLocalBit = 0x80000000u;
+
 __device__ inline uint32_t lcp(uint64_t a, uint64_t b) {           // accel_build.cu:53-55
     uint64_t x = a ^ b;
     return x ? (uint32_t)__builtin_clzll(x) : 64u;
@@ -265,8 +267,10 @@ __global__ void __launch_bounds__(kBlock) k_karras(AccelNode *__restrict__ nodes
     if (lc == first) lc += n - 1;
     if (rc == last) rc += n - 1;
     nodes[index] = AccelNode{lc, rc};
-    parents[lc] = index;
-    parents[rc] = index;
+    // bit 31 marks a parent whose whole leaf range lies inside one refit workgroup's 256 leaves
+    uint32_t tag = (first / kBlock == last / kBlock) ? (index | kLocalBit) : index;
+    parents[lc] = tag;
+    parents[rc] = tag;
 }
 
 // Total order on floats in which -0 sorts below +0: the order the reference's integer-atomic
@@ -278,53 +282,147 @@ __device__ inline uint32_t order_key(float f) {
 __device__ inline float tmin(float a, float b) { return order_key(b) < order_key(a) ? b : a; }
 __device__ inline float tmax(float a, float b) { return order_key(b) > order_key(a) ? b : a; }
 
-__device__ inline float load_sc1(const float *p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Device-scope 16-byte accesses that bypass the per-CU cache (loads) or write through to memory
+// (stores).  A box is two of them; one wide access costs the fabric a quarter of what four
+// dword accesses of the same kind do.  Inline asm is outside the compiler's wait-count
+// bookkeeping, so each statement carries its own wait.
+__device__ inline void load_box_sc1(const Bbox *p, f32x4 &lo, f32x4 &hi) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(p)
+                 : "memory");
 }
-__device__ inline void store_sc1(float *p, float v) {
-    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline void store_box_sc1(Bbox *p, f32x4 lo, f32x4 hi) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "global_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 :
+                 : "v"(p), "v"(lo), "v"(hi)
+                 : "memory");
 }
 
 // Bottom-up refit: one lane per leaf climbs towards the root; at every parent the first arrival
-// stops and the second merges both children.  A child box produced inside this launch is
-// written with device-scope write-through stores, drained, and only then announced by the
-// arrival counter; the merging lane reads the sibling with device-scope loads that bypass the
-// per-CU cache, so no cache-wide fence is needed and the result does not depend on where the
-// two lanes run.
+// stops and the second merges both children.
+//
+// Leaves are in sorted order and an internal node's index is one end of its leaf range, so a
+// node whose range lies inside the 256 leaves of one workgroup is only ever touched by that
+// workgroup and owns the LDS slot (index - first leaf of the workgroup).  Those nodes -- all but
+// a few per workgroup -- hand their boxes over through LDS with workgroup-scope atomics.  Only
+// nodes whose range crosses a workgroup boundary use memory: the child box is written with
+// device-scope write-through stores, drained, and then announced by a device-scope arrival
+// counter; the merging lane reads the sibling with device-scope loads that bypass the per-CU
+// cache.  No cache-wide fence is needed and the result does not depend on where lanes run.
 __global__ void __launch_bounds__(kBlock) k_refit(const uint32_t *__restrict__ parents, const AccelNode *__restrict__ nodes, Bbox *bboxes,
                                                    uint32_t *arrivals, Bbox merged, uint32_t n) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float s_box[kBlock][6];          // boxes of finished internal nodes, slot = node index - block_first
+    __shared__ float s_leaf[kBlock][6];         // this workgroup's leaf boxes
+    __shared__ uint2 s_nodes[kBlock];           // children of internal nodes block_first .. block_first + 255
+    __shared__ uint32_t s_parent[kBlock];       // their parent tags
+    __shared__ uint32_t s_arrivals[kBlock];
+    const uint32_t block_first = blockIdx.x * kBlock;
+    const uint32_t i = block_first + threadIdx.x;
+    s_arrivals[threadIdx.x] = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (i < n) {
+        const float4 *lb = reinterpret_cast<const float4 *>(bboxes + (n - 1) + i);
+        float4 lo4 = lb[0], hi4 = lb[1];
+        lo[0] = lo4.x; lo[1] = lo4.y; lo[2] = lo4.z; hi[0] = hi4.x; hi[1] = hi4.y; hi[2] = hi4.z;
+        float *sl = s_leaf[threadIdx.x];
+        sl[0] = lo[0]; sl[1] = lo[1]; sl[2] = lo[2]; sl[3] = hi[0]; sl[4] = hi[1]; sl[5] = hi[2];
+    }
+    if (i < n - 1) {
+        AccelNode nd = nodes[i];
+        s_nodes[threadIdx.x] = make_uint2(nd.lc_or_id, nd.rc);
+        s_parent[threadIdx.x] = i > 0 ? parents[i] : 0u;
+    }
+    __syncthreads();
     if (i >= n) return;
     uint32_t cur = (n - 1) + i;
-    const float4 *lb = reinterpret_cast<const float4 *>(bboxes + cur);
-    float4 lo4 = lb[0], hi4 = lb[1];
-    float lo[3] = {lo4.x, lo4.y, lo4.z}, hi[3] = {hi4.x, hi4.y, hi4.z};
+    bool cur_internal = false;
     // internal boxes start from the inverted merged box (accel_build.cu:140-148)
     const float init_lo[3] = {merged.pmax.x, merged.pmax.y, merged.pmax.z};
     const float init_hi[3] = {merged.pmin.x, merged.pmin.y, merged.pmin.z};
-    while (cur != 0) {
-        uint32_t pa = parents[cur];
-        uint32_t seen = __hip_atomic_fetch_add(&arrivals[pa], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t tag = parents[cur];
+    for (;;) {
+        const uint32_t cslot = cur - block_first;
+        const uint32_t pa = tag & ~kLocalBit;
+        const bool local = (tag & kLocalBit) != 0;
+        // The parent's children and its own parent tag are read-only here (written by earlier
+        // kernels): fetch them now so that the loads overlap the hand-off below.
+        const uint32_t pslot = pa - block_first;
+        uint2 nd;
+        uint32_t next_tag = 0;
+        if (pslot < kBlock) {
+            nd = s_nodes[pslot];
+            next_tag = s_parent[pslot];
+        } else {
+            AccelNode g = nodes[pa];
+            nd = make_uint2(g.lc_or_id, g.rc);
+            if (pa != 0) next_tag = parents[pa];
+        }
+        uint32_t seen;
+        if (local) {
+            if (cur_internal) {
+                float *sb = s_box[cslot];
+                sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
+                float4 *gb = reinterpret_cast<float4 *>(bboxes + cur);
+                gb[0] = make_float4(lo[0], lo[1], lo[2], merged.pmax.w);
+                gb[1] = make_float4(hi[0], hi[1], hi[2], merged.pmin.w);
+            }
+            seen = __hip_atomic_fetch_add(&s_arrivals[pslot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (cur_internal) {
+                f32x4 olo = {lo[0], lo[1], lo[2], merged.pmax.w}, ohi = {hi[0], hi[1], hi[2], merged.pmin.w};
+                store_box_sc1(bboxes + cur, olo, ohi);
+            }
+            seen = __hip_atomic_fetch_add(&arrivals[pa], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (seen == 0) return;
-        AccelNode nd = nodes[pa];
-        uint32_t sib = nd.lc_or_id == cur ? nd.rc : nd.lc_or_id;
-        const float *sb = reinterpret_cast<const float *>(bboxes + sib);
-        float *pb = reinterpret_cast<float *>(bboxes + pa);
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = tmin(init_lo[a], tmin(lo[a], load_sc1(sb + a)));
-            hi[a] = tmax(init_hi[a], tmax(hi[a], load_sc1(sb + 4 + a)));
+        const uint32_t sib = nd.x == cur ? nd.y : nd.x;
+        float slo[3], shi[3];
+        if (sib >= n - 1) {                       // a leaf: written by an earlier kernel
+            const uint32_t lslot = sib - (n - 1) - block_first;
+            if (lslot < kBlock) {
+                const float *sl = s_leaf[lslot];
+                slo[0] = sl[0]; slo[1] = sl[1]; slo[2] = sl[2]; shi[0] = sl[3]; shi[1] = sl[4]; shi[2] = sl[5];
+            } else {
+                const float4 *sp = reinterpret_cast<const float4 *>(bboxes + sib);
+                float4 a4 = sp[0], b4 = sp[1];
+                slo[0] = a4.x; slo[1] = a4.y; slo[2] = a4.z; shi[0] = b4.x; shi[1] = b4.y; shi[2] = b4.z;
+            }
+        } else if (local) {
+            const float *sb = s_box[sib - block_first];
+            slo[0] = sb[0]; slo[1] = sb[1]; slo[2] = sb[2]; shi[0] = sb[3]; shi[1] = sb[4]; shi[2] = sb[5];
+        } else {
+            f32x4 a4, b4;
+            load_box_sc1(bboxes + sib, a4, b4);
+            slo[0] = a4[0]; slo[1] = a4[1]; slo[2] = a4[2]; shi[0] = b4[0]; shi[1] = b4[1]; shi[2] = b4[2];
         }
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            store_sc1(pb + a, lo[a]);
-            store_sc1(pb + 4 + a, hi[a]);
+            lo[a] = tmin(init_lo[a], tmin(lo[a], slo[a]));
+            hi[a] = tmax(init_hi[a], tmax(hi[a], shi[a]));
         }
-        store_sc1(pb + 3, merged.pmax.w);
-        store_sc1(pb + 7, merged.pmin.w);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur = pa;
+        cur_internal = true;
+        tag = next_tag;
+        if (cur == 0) {
+            float4 *gb = reinterpret_cast<float4 *>(bboxes);
+            gb[0] = make_float4(lo[0], lo[1], lo[2], merged.pmax.w);
+            gb[1] = make_float4(hi[0], hi[1], hi[2], merged.pmin.w);
+            return;
+        }
     }
+}
+
+// parent links without the locality tag, for callers that ask for the reference's parents array
+__global__ void __launch_bounds__(kBlock) k_strip_parents(uint32_t *__restrict__ out, const uint32_t *__restrict__ parents, uint32_t count) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 1 && i < count) out[i] = parents[i] & ~kLocalBit;
 }
 
 // ---- packing into traversal records --------------------------------------------------------
@@ -471,7 +569,7 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     }
     mark(5);
     if (keys_out) HIP_OK(hipMemcpyAsync(keys_out, src, 8 * (size_t)n, hipMemcpyDeviceToDevice, stream));
-    if (parents_out && n > 1) HIP_OK(hipMemcpyAsync(parents_out, parents, 4 * (size_t)(2 * n - 1), hipMemcpyDeviceToDevice, stream));
+    if (parents_out && n > 1) hipLaunchKernelGGL(k_strip_parents, dim3(cdiv(2 * n - 1, kBlock)), dim3(kBlock), 0, stream, parents_out, parents, 2 * n - 1);
     HIP_OK(hipGetLastError());
     if (stage_ms) {
         HIP_OK(hipStreamSynchronize(stream));
