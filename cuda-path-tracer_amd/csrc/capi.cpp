@@ -301,6 +301,12 @@ void cpt_tracer_destroy(cpt_tracer *t) { delete t; }
 
 int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth) { TRACER_OR_FAIL(t); t->tracer->SetMaxDepth(max_depth); return CPT_OK; }
 int cpt_tracer_set_channel(cpt_tracer *t, int channel) { TRACER_OR_FAIL(t); t->tracer->SetChannel(channel); return CPT_OK; }
+int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
+    TRACER_OR_FAIL(t);
+    if (mode != 0 && mode != 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0 or 1");
+    t->tracer->SetIntegrator(mode);
+    return CPT_OK;
+}
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on) { TRACER_OR_FAIL(t); t->tracer->SetProfileBuild(on != 0); return CPT_OK; }
 int cpt_tracer_build_buffers(cpt_tracer *t) {
     TRACER_OR_FAIL(t);

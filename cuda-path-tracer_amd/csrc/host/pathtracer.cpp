@@ -253,8 +253,25 @@ void PathTracer::Update() {
     p.max_depth = static_cast<uint32_t>(max_depth_);
     p.channel = display_channel_;
     p.sum_mode = 0;
-    rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
+    LaunchSample(p);
     film_.DeviceUnmap();
+}
+
+void PathTracer::LaunchSample(const cpt::RenderParams &p) {
+    if (integrator_ == 1) {
+        rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
+        return;
+    }
+    if (!queue_.Size()) {
+        queue_.Allocate(2 * sizeof(uint32_t));
+        queue_.Zero(stream_);
+        queue_parity_ = 0;
+        int device = 0;
+        CPT_HIP(hipGetDevice(&device));
+        resident_blocks_ = cpt::render_regen_resident_blocks(device);
+    }
+    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, stream_), "render");
+    queue_parity_ ^= 1u;
 }
 
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
@@ -268,7 +285,7 @@ void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode
     p.sum_mode = sum_mode ? 1 : 0;
     for (uint32_t s = 0; s < count; s++) {
         p.spp = spp_begin + s;
-        rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
+        LaunchSample(p);
     }
 }
 

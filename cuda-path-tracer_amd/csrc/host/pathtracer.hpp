@@ -29,6 +29,8 @@ public:
 
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
+    // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel
+    void SetIntegrator(int mode) { integrator_ = mode; }
     void Synchronize();
     uint32_t CurrentSpp() const { return curr_spp_; }
     uint32_t NumLights() const { return num_lights_; }
@@ -74,6 +76,11 @@ private:
     uint32_t last_width_ = 0, last_height_ = 0;
     bool built_ = false, has_camera_ = false;
     bool profile_build_ = false;
+    int integrator_ = 0;
+    uint32_t queue_parity_ = 0;
+    int resident_blocks_ = 0;
+    cpt::HipBuffer queue_;
+    void LaunchSample(const cpt::RenderParams &p);
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 
     cpt::BuildWorkspace workspace_;

@@ -10,6 +10,13 @@ namespace cpt {
 // without the trailing device synchronisation.
 int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream);
 
+// The same sample through the persistent, lane-regenerating kernel.  `queue` is a device array of
+// two uint32 counters owned by the caller: queue[parity] must be zero when the launch starts (the
+// kernel zeroes queue[parity ^ 1] for the next launch, so alternate parity 0,1,0,.. on one stream
+// after zeroing both once).  max_blocks: render_regen_resident_blocks() of the device.
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream);
+int render_regen_resident_blocks(int device);
+
 // rays: device array of n * 8 floats (origin.xyz, tmin, direction.xyz, tmax).
 // inst/prim receive 0xffffffff on a miss; t receives the hit distance (or the input tmax);
 // t and uv may be null.

@@ -62,7 +62,7 @@ constexpr float kShadowRayEps = 0.001f;
 __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, TraceStack &st, LaneCounters &cnt) {
     Hit hit;
     float tmax = kRayTMax;
-    if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
+    if (!trace<false>(sc, true, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
     Surface surface = shading_surface(sc, hit, cnt);
     if (channel == 1) return surface.vertex.normal * 0.5f + v3(0.5f);
     V3 color = surface.bsdf.emission;
@@ -82,7 +82,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
             if (ls.pdf > 0.0f) {
                 Hit dummy;
                 float smax = ls.dist - kShadowRayEps;
-                if (!trace<true>(sc, surface.vertex.position, ls.dir, kRayTMin, smax, dummy, st, cnt)) {
+                if (!trace<true>(sc, true, surface.vertex.position, ls.dir, kRayTMin, smax, dummy, st, cnt)) {
                     V3 wi = frame.to_local(ls.dir);
                     float bp = bsdf_pdf(surface.bsdf, wo, wi);
                     float mis_weight = power_heuristic(ls.pdf, bp);      // area lights are never delta
@@ -99,7 +99,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
         ro = surface.vertex.position;
         rd = frame.to_world(bs.wi);
         tmax = kRayTMax;
-        if (!trace<false>(sc, ro, rd, kRayTMin, tmax, hit, st, cnt)) break;
+        if (!trace<false>(sc, true, ro, rd, kRayTMin, tmax, hit, st, cnt)) break;
 
         surface = shading_surface(sc, hit, cnt);
         if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
@@ -182,6 +182,168 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
     flush_counters(sc, cnt, active ? 1u : 0u, s_cnt);
 }
 
+constexpr uint32_t kBatchSlots = 256;     // pixel slots (four 8x8 tiles) a wave takes from the queue at a time
+
+// Persistent variant of the same integrator: every lane still follows exactly one path at a
+// time with the reference's operation order, but a lane whose path ends picks up the next pixel
+// at once instead of idling until the slowest path of its wave is done.  Pixel slots (8x8 tiles,
+// 64 consecutive slots each) are handed out in batches through one device-wide counter; idle
+// lanes are found with a ballot and numbered with a popcount prefix.  One trip of the loop is:
+// closest-hit trace for every live lane (camera rays and bounce rays mixed), shading + light
+// sampling, any-hit trace for the lanes with a shadow ray, BSDF sampling.
+__global__ void __launch_bounds__(kTraceBlock) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    uint32_t paths = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    const uint32_t total_slots = tiles_x * tiles_y * 64;
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue[parity ^ 1u] = 0;     // the next launch's counter
+
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+    // per-lane path state
+    bool alive = false, primary = false, last_specular = false;
+    uint32_t pixel_index = 0, depth = 0;
+    float last_pdf = 0.0f;
+    Sampler sampler{0};
+    V3 ro = v3(0.0f), rd = v3(0.0f), throughput = v3(0.0f), color = v3(0.0f);
+
+    for (;;) {
+        // ---- hand new pixels to idle lanes
+        unsigned long long idle = __ballot(!alive);
+        while (idle != 0ull && !exhausted) {
+            if (next >= end) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&queue[parity], kBatchSlots);
+                b = __shfl(b, 0, 64);
+                if (b >= total_slots) { exhausted = true; break; }
+                next = b;
+                end = min(b + kBatchSlots, total_slots);
+            }
+            const uint32_t rank = __popcll(idle & lt_mask);
+            const uint32_t take = min((uint32_t)__popcll(idle), end - next);
+            if (!alive && rank < take) {
+                const uint32_t slot = next + rank;
+                const uint32_t tile = slot >> 6, k = slot & 63u;
+                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                if (px < p.width && py < p.height) {
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
+                    alive = true; primary = true; last_specular = false;
+                    depth = 0; color = v3(0.0f); throughput = v3(1.0f);
+                    paths++;
+                }
+            }
+            next += take;
+            idle = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull) break;        // nothing in flight and the queue is empty
+
+        // ---- extend
+        Hit hit;
+        float tmax = kRayTMax;
+        const bool got = trace<false>(sc, alive, ro, rd, kRayTMin, tmax, hit, st, cnt);
+
+        // ---- shade, pick a light sample (src/kernels/integrator/path.cu:9-48, :57-80)
+        bool finish = false, need_shadow = false;
+        V3 pos = v3(0.0f), normal = v3(0.0f, 0.0f, 1.0f), ldir = v3(0.0f), lweight = v3(0.0f);
+        float lpdf = 0.0f, ldist = 0.0f;
+        uint32_t material = 0;
+        if (alive) {
+            if (!got) {
+                finish = true;
+            } else {
+                Surface surface = shading_surface(sc, hit, cnt);
+                if (primary) {
+                    primary = false;
+                    if (p.channel == 1) { color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
+                    else { color = surface.bsdf.emission; if (!is_zero(color)) finish = true; }
+                } else if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
+                    float mis_weight = 1.0f;
+                    if (!last_specular) {
+                        float light_pdf = surface.vertex.pdf * path_to_solid_angle_jacobian(ro, surface.vertex.position, surface.vertex.normal) *
+                                          sc.light_pick_pdf;
+                        mis_weight = power_heuristic(last_pdf, light_pdf);
+                    }
+                    color = color + throughput * mis_weight * surface.bsdf.emission;
+                    finish = true;
+                } else {
+                    float rr_prop = gmin(gmax(luminance(throughput), 0.01f), 0.95f);
+                    if (sampler.next1d() > rr_prop) finish = true;
+                    else { throughput = throughput / rr_prop; depth++; }
+                }
+                if (!finish && !(depth < p.max_depth)) finish = true;
+                if (!finish) {
+                    pos = surface.vertex.position;
+                    normal = surface.vertex.normal;
+                    material = sc.instances[hit.inst].material;
+                    if (!bsdf_is_delta(surface.bsdf)) {
+                        float r1 = sampler.next1d();
+                        uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
+                        V2 r2 = sampler.next2d();
+                        LightSample ls = light_sample(sc, sc.lights[index], pos, r2);
+                        ls.pdf *= sc.light_pick_pdf;
+                        ls.weight = ls.weight / sc.light_pick_pdf;
+                        if (ls.pdf > 0.0f) { need_shadow = true; ldir = ls.dir; lweight = ls.weight; lpdf = ls.pdf; ldist = ls.dist; }
+                    }
+                }
+            }
+        }
+
+        // ---- shadow rays
+        Hit dummy;
+        float smax = ldist - kShadowRayEps;
+        const bool occluded = trace<true>(sc, need_shadow, pos, ldir, kRayTMin, smax, dummy, st, cnt);
+
+        // ---- light contribution and next direction (path.cu:38-55)
+        if (alive && !finish) {
+            const BsdfDev bsdf = sc.materials[material];
+            Frame frame = Frame::from_normal(normal);
+            V3 wo = frame.to_local(-rd);
+            if (need_shadow && !occluded) {
+                V3 wi = frame.to_local(ldir);
+                float bp = bsdf_pdf(bsdf, wo, wi);
+                float mis_weight = power_heuristic(lpdf, bp);
+                color = color + throughput * mis_weight * lweight * bsdf_eval(bsdf, wo, wi);
+            }
+            float b1 = sampler.next1d();
+            V2 b2 = sampler.next2d();
+            BsdfSample bs = bsdf_sample(bsdf, wo, b1, b2);
+            if (bs.pdf == 0.0f) {
+                finish = true;
+            } else {
+                throughput = throughput * bs.weight;
+                ro = pos;
+                rd = frame.to_world(bs.wi);
+                last_pdf = bs.pdf;
+                last_specular = bs.lobe == kLobeSpecular;
+            }
+        }
+
+        // ---- film (path.cu:99-104)
+        if (alive && finish) {
+            V3 c = color;
+            if (isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z)) c = v3(0.0f);
+            float4 *out = reinterpret_cast<float4 *>(p.output) + pixel_index;
+            float4 prev = *out;
+            float4 res;
+            if (p.sum_mode) {
+                res = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
+            } else {
+                float a = 1.0f / (float)p.spp;
+                res = make_float4(prev.x * (1.0f - a) + c.x * a, prev.y * (1.0f - a) + c.y * a, prev.z * (1.0f - a) + c.z * a, prev.w * (1.0f - a) + 1.0f * a);
+            }
+            *out = res;
+            alive = false;
+        }
+    }
+    flush_counters(sc, cnt, paths, s_cnt);
+}
+
 __global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
@@ -195,7 +357,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const fl
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        bool ok = trace<false>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
+        bool ok = trace<false>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
         inst_out[i] = ok ? hit.inst : 0xffffffffu;
         prim_out[i] = ok ? hit.prim : 0xffffffffu;
         if (t_out) t_out[i] = tmax;
@@ -216,7 +378,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_occlude(SceneDev sc, const floa
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        out[i] = trace<true>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
+        out[i] = trace<true>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
     }
     flush_counters(sc, cnt, 0u, s_cnt);
 }
@@ -241,6 +403,22 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
     if (tiles == 0) return 0;
     hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
     return (int)hipGetLastError();
+}
+
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream) {
+    uint32_t slots = ((p.width + 7) / 8) * ((p.height + 7) / 8) * 64;
+    if (slots == 0) return 0;
+    uint32_t want = (slots + kBatchSlots * (kTraceBlock / 64) - 1) / (kBatchSlots * (kTraceBlock / 64));
+    uint32_t blocks = want < max_blocks ? want : max_blocks;
+    hipLaunchKernelGGL(k_render_regen, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
+    return (int)hipGetLastError();
+}
+
+int render_regen_resident_blocks(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_regen, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return per_cu * cus;
 }
 
 int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, hipStream_t stream) {

@@ -86,66 +86,100 @@ __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, fl
     return false;
 }
 
+constexpr uint32_t kNoNode = 0xffffffffu;
+
 // Closest hit (ANY = false; AccelTop::Intersect, accel.cuh:124-150) or any hit (ANY = true;
 // AccelTop::Occlude, accel.cuh:152-173).  tmax is updated to the hit distance on closest hits.
+//
+// All lanes of the wave that reach this call run it together (`active` = false for lanes with
+// nothing to trace).  Each lane is in one of three states -- at an internal node, at a triangle,
+// at an instance leaf -- and every trip of the loop the wave votes (ballot + popcount) for the
+// state most lanes are in and executes only that step; the other lanes wait with their state
+// intact.  A lane's own sequence of box tests, triangle tests and stack operations is exactly the
+// sequential one, so results do not depend on the vote, but the expensive node step always runs
+// with as many lanes as possible instead of being serialised with the other two every trip.
 template <bool ANY>
-__device__ inline bool trace(const SceneDev &sc, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
-    cnt.rays++;
-    const AccelRoot troot = *sc.top_root;
-    float t0;
-    if (!(slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], ow, dw, tmin, t0) && t0 < tmax))
-        return false;
-    uint32_t cur = troot.ref;
+__device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
+    uint32_t cur = kNoNode;
     bool in_blas = false, found = false;
     uint32_t sp = 0, sp_base = 0, inst_id = 0;
     V3 o = ow, d = dw;
     const PackedNode *nodes = sc.top_nodes;
     const TriRecord *tris = nullptr;
+    if (active) {
+        cnt.rays++;
+        const AccelRoot troot = *sc.top_root;
+        float t0;
+        if (slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], ow, dw, tmin, t0) && t0 < tmax) cur = troot.ref;
+    }
     for (;;) {
-        if (!(cur & kLeafBit)) {
-            const float4 *q = reinterpret_cast<const float4 *>(nodes + cur);
-            float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            cnt.nodes++;
-            float t0l, t0r;
-            bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tmin, t0l);
-            bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tmin, t0r);
-            if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
-            if (hr && t0r < tmax) { cur = __float_as_uint(q3.y); continue; }
-        } else if (in_blas) {
-            float t, bv, bw;
-            uint32_t prim;
-            cnt.tris++;
-            if (tri_test(tris + (cur & ~kLeafBit), o, d, tmin, tmax, t, bv, bw, prim)) {
-                if (ANY) return true;
-                tmax = t;
-                hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
-                found = true;
+        const bool live = cur != kNoNode;
+        const bool is_node = live && !(cur & kLeafBit);
+        const bool is_tri = live && (cur & kLeafBit) && in_blas;
+        const bool is_inst = live && (cur & kLeafBit) && !in_blas;
+        const unsigned long long mn = __ballot(is_node), mt = __ballot(is_tri), mi = __ballot(is_inst);
+        if ((mn | mt | mi) == 0ull) break;
+        const int cn = __popcll(mn), ct = __popcll(mt), ci = __popcll(mi);
+        bool need_pop = false;
+        if (cn >= ct && cn >= ci) {
+            if (is_node) {
+                const float4 *q = reinterpret_cast<const float4 *>(nodes + cur);
+                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                cnt.nodes++;
+                float t0l, t0r;
+                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tmin, t0l);
+                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tmin, t0r);
+                if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                else need_pop = true;
+            }
+        } else if (ct >= ci) {
+            if (is_tri) {
+                float t, bv, bw;
+                uint32_t prim;
+                cnt.tris++;
+                need_pop = true;
+                if (tri_test(tris + (cur & ~kLeafBit), o, d, tmin, tmax, t, bv, bw, prim)) {
+                    found = true;
+                    if (ANY) {
+                        need_pop = false;
+                        cur = kNoNode;
+                    } else {
+                        tmax = t;
+                        hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                    }
+                }
             }
         } else {
-            inst_id = cur & ~kLeafBit;
-            const InstanceDev &in = sc.instances[inst_id];
-            M4 inv = in.transform_inv;
-            o = xyz(mul(inv, v4(ow, 1.0f)));
-            d = xyz(mul(inv, v4(dw, 0.0f)));
-            const MeshDev &m = sc.meshes[in.mesh];
-            nodes = m.nodes;
-            tris = m.tris;
-            AccelRoot r = m.root;
-            in_blas = true;
-            sp_base = sp;
-            if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], o, d, tmin, t0) && t0 < tmax) {
-                cur = r.ref;
-                continue;
+            if (is_inst) {
+                inst_id = cur & ~kLeafBit;
+                const InstanceDev &in = sc.instances[inst_id];
+                M4 inv = in.transform_inv;
+                o = xyz(mul(inv, v4(ow, 1.0f)));
+                d = xyz(mul(inv, v4(dw, 0.0f)));
+                const MeshDev &m = sc.meshes[in.mesh];
+                nodes = m.nodes;
+                tris = m.tris;
+                AccelRoot r = m.root;
+                in_blas = true;
+                sp_base = sp;
+                float t0;
+                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], o, d, tmin, t0) && t0 < tmax) cur = r.ref;
+                else need_pop = true;
             }
         }
-        for (;;) {
-            if (in_blas && sp == sp_base) { in_blas = false; o = ow; d = dw; nodes = sc.top_nodes; }
-            if (sp == 0) return found;
-            --sp;
-            uint2 e = st.at(sp);
-            if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+        if (need_pop) {
+            cur = kNoNode;
+            for (;;) {
+                if (in_blas && sp == sp_base) { in_blas = false; o = ow; d = dw; nodes = sc.top_nodes; }
+                if (sp == 0) break;
+                --sp;
+                uint2 e = st.at(sp);
+                if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+            }
         }
     }
+    return found;
 }
 
 }  // namespace cpt

@@ -100,6 +100,10 @@ cpt_tracer *cpt_tracer_create(cpt_scene *s, uint32_t film_width, uint32_t film_h
 void cpt_tracer_destroy(cpt_tracer *t);
 int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth);         /* -1 = unbounded, Russian roulette only */
 int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour, 1 shading normal */
+/* Bounce-loop kernel: 0 = persistent megakernel whose lanes pick up a new pixel as soon as their
+ * path ends (default); 1 = one lane per pixel for the whole launch, the structure of the
+ * reference's RenderKernel (src/kernels/integrator/path.cu:85-105).  Same image either way. */
+int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
 int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */
 int cpt_tracer_update(cpt_tracer *t);                               /* PathTracer::Update: one more sample per pixel (asynchronous) */

@@ -134,3 +134,18 @@ def test_cli_renders_an_exr(cpt, tmp_path):
     objs, c = cornell(glass=False)
     ref, _ = OracleScene(objs, c).render(64, 48, 1, 33, 5)
     compare(img, ref)
+
+
+def test_both_kernels_give_the_same_image_bit_for_bit(cpt):
+    """The persistent lane-regenerating kernel and the one-lane-per-pixel kernel run the same
+    per-path operation sequence, so their films must be identical, not merely close."""
+    objs, cam = cornell(glass=True)
+    imgs = []
+    for mode in (0, 1):
+        sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=8)     # not a multiple of the 8x8 tiles
+        tr.set_integrator(mode)
+        tr.update(6)
+        imgs.append(tr.film())
+        c = tr.counters()
+        assert c["paths"] == 200 * 120 * 6
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
