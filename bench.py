@@ -81,7 +81,7 @@ def cpu_baseline(width, height, max_depth, glass=True, target_seconds=12.0):
     t0 = time.perf_counter()
     osc.render(width, height, 1, 2, max_depth, nthreads=cores)
     one = time.perf_counter() - t0
-    spp = int(max(1, min(32, target_seconds / max(one, 1e-3))))
+    spp = int(max(1, min(256, target_seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     _, cnt = osc.render(width, height, 2, 2 + spp, max_depth, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the N>1 code path with every rank on GPU 0 and the reduce over gloo (functional rehearsal, not a measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,10 +111,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cpt = load_cpt()
     cpt.check(cpt.lib.cpt_set_device(local_rank))
@@ -148,18 +155,29 @@ def main():
         begin, count = sharding.sample_block(rank, world, K)
         barrier()
         t0 = time.perf_counter()
+        tracer.timer_begin()
         tracer.render_samples(begin, count, True, accum.data_ptr(), W, H)
-        tracer.synchronize()
-        sharding.reduce_sum_to_root(accum, dst=0)
+        kernel_ms = tracer.timer_end()          # this rank's K launches, HIP events on the launch stream
+        if args.rehearse_on_one_gpu:
+            host = accum.cpu()
+            sharding.reduce_sum_to_root(host, dst=0)
+            accum.copy_(host)
+        else:
+            sharding.reduce_sum_to_root(accum, dst=0)
         barrier()
         elapsed = time.perf_counter() - t0
+        if rank == 0:
+            alpha = accum[..., 3]
+            if not bool(torch.all(alpha == float(K * world))):
+                raise SystemExit("reduced film does not hold K x N samples per pixel")
 
     counters = tracer.counters()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else device
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([counters[k] for k in ("rays", "node_visits", "tri_tests", "paths", "shades")], dtype=torch.int64, device=device)
+        cnt = torch.tensor([counters[k] for k in ("rays", "node_visits", "tri_tests", "paths", "shades")], dtype=torch.int64, device=red_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total = dict(zip(("rays", "node_visits", "tri_tests", "paths", "shades"), [int(x) for x in cnt.tolist()]))
     else:
@@ -181,22 +199,22 @@ def main():
             "dtype": "f32",
             "data": "reference scene file cornell-box-glass (committed fixture); synthetic soups for the LBVH timings",
             "config": {"workload": f"cornell-box-glass {W}x{H}, max-depth {args.max_depth}, glass box, 1 spp per step, {K} spp per GPU",
-                       "integrator": "megakernel", "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks + 1 sum-reduce"},
+                       "integrator": "persistent megakernel (lane regeneration)", "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks + 1 sum-reduce"},
             "mrays_per_s": round(total["rays"] / elapsed / 1e6, 3),
             "rays_per_path": round(total["rays"] / max(total["paths"], 1), 4),
         }
         if kernel_ms is not None:
-            per_launch_bytes = algorithmic_bytes(total, W * H, K)
+            per_launch_bytes = algorithmic_bytes(counters, W * H, K)     # rank 0's own launches
             avg_ms = kernel_ms / K
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("k_render_hbm_bytes_per_launch")
+                    traffic = json.load(open(tpath)).get("k_render_regen_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            result["roofline"] = {"kernel": "k_render", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            result["roofline"] = {"kernel": "k_render_regen", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         if world == 1 and not args.no_lbvh:

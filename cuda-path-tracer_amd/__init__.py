@@ -69,6 +69,8 @@ _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
 _sig("cpt_tracer_update", C.c_int, [_vp])
 _sig("cpt_tracer_update_timed", C.c_int, [_vp, C.c_uint32, _vp])
+_sig("cpt_tracer_timer_begin", C.c_int, [_vp])
+_sig("cpt_tracer_timer_end", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_accumulation", C.c_int, [_vp])
 _sig("cpt_tracer_synchronize", C.c_int, [_vp])
 _sig("cpt_tracer_current_spp", C.c_uint32, [_vp])
@@ -280,6 +282,14 @@ class Tracer:
         """n Update calls; returns the device milliseconds measured on the tracer's stream."""
         ms = C.c_float(0.0)
         check(lib.cpt_tracer_update_timed(self.h, n, C.byref(ms)))
+        return ms.value
+
+    def timer_begin(self):
+        check(lib.cpt_tracer_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float(0.0)
+        check(lib.cpt_tracer_timer_end(self.h, C.byref(ms)))
         return ms.value
 
     def reset(self):

@@ -393,6 +393,16 @@ int cpt_tracer_update_timed(cpt_tracer *t, uint32_t count, float *elapsed_ms) {
     return Guard([&] { *elapsed_ms = t->tracer->UpdateTimed(count); return CPT_OK; });
 }
 
+int cpt_tracer_timer_begin(cpt_tracer *t) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->TimerBegin(); return CPT_OK; });
+}
+int cpt_tracer_timer_end(cpt_tracer *t, float *elapsed_ms) {
+    TRACER_OR_FAIL(t);
+    if (!elapsed_ms) return Fail(CPT_ERR_INVALID, "cpt_tracer_timer_end: null argument");
+    return Guard([&] { *elapsed_ms = t->tracer->TimerEnd(); return CPT_OK; });
+}
+
 int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]) {
     TRACER_OR_FAIL(t);
     return Guard([&] {

@@ -293,6 +293,21 @@ void PathTracer::Synchronize() {
     if (stream_) CPT_HIP(hipStreamSynchronize(stream_));
 }
 
+void PathTracer::TimerBegin() {
+    if (!stream_) return;
+    if (!ev_begin_) { CPT_HIP(hipEventCreate(&ev_begin_)); CPT_HIP(hipEventCreate(&ev_end_)); }
+    CPT_HIP(hipEventRecord(ev_begin_, stream_));
+}
+
+float PathTracer::TimerEnd() {
+    if (!stream_ || !ev_begin_) return 0.0f;
+    CPT_HIP(hipEventRecord(ev_end_, stream_));
+    CPT_HIP(hipEventSynchronize(ev_end_));
+    float ms = 0.0f;
+    CPT_HIP(hipEventElapsedTime(&ms, ev_begin_, ev_end_));
+    return ms;
+}
+
 float PathTracer::UpdateTimed(uint32_t count) {
     if (!stream_) return 0.0f;
     if (!ev_begin_) { CPT_HIP(hipEventCreate(&ev_begin_)); CPT_HIP(hipEventCreate(&ev_end_)); }

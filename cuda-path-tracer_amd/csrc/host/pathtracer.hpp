@@ -43,6 +43,9 @@ public:
     void ReadCounters(unsigned long long out[5]);
     // `count` Update() calls bracketed by events on the tracer's stream; returns device milliseconds
     float UpdateTimed(uint32_t count);
+    // device time between two points of the tracer's stream: TimerBegin records, TimerEnd records, waits and returns ms
+    void TimerBegin();
+    float TimerEnd();
     void ResetCounters();
 
     struct AccelView { const cpt::AccelNode *nodes; const cpt::Bbox *bboxes; const uint64_t *keys; uint32_t num_primitives; };

@@ -191,7 +191,7 @@ constexpr uint32_t kBatchSlots = 256;     // pixel slots (four 8x8 tiles) a wave
 // lanes are found with a ballot and numbered with a popcount prefix.  One trip of the loop is:
 // closest-hit trace for every live lane (camera rays and bounce rays mixed), shading + light
 // sampling, any-hit trace for the lanes with a shadow ray, BSDF sampling.
-__global__ void __launch_bounds__(kTraceBlock) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
+__global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     TraceStack st;

@@ -18,8 +18,8 @@
 
 namespace cpt {
 
-constexpr int kLdsStackEntries = 24;   // per lane, in LDS: 24 * 8 B * 256 lanes = 48 KB per workgroup
-constexpr int kSpillEntries = 40;      // per lane, private memory, touched only by very deep trees
+constexpr int kLdsStackEntries = 16;   // per lane, in LDS: 16 * 8 B * 256 lanes = 32 KB per workgroup
+constexpr int kSpillEntries = 48;      // per lane, private memory, touched only by very deep trees
 constexpr int kTraceBlock = 256;
 
 struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; };

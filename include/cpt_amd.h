@@ -110,6 +110,10 @@ int cpt_tracer_update(cpt_tracer *t);                               /* PathTrace
 /* `count` Update calls bracketed by HIP events on the tracer's own stream; elapsed_ms receives the
  * device time of the whole batch.  Synchronises. */
 int cpt_tracer_update_timed(cpt_tracer *t, uint32_t count, float *elapsed_ms);
+/* HIP-event stopwatch on the tracer's stream: begin records an event, end records another, waits
+ * for it and returns the device milliseconds between the two. */
+int cpt_tracer_timer_begin(cpt_tracer *t);
+int cpt_tracer_timer_end(cpt_tracer *t, float *elapsed_ms);
 int cpt_tracer_reset_accumulation(cpt_tracer *t);                   /* PathTracer::ResetAccumelation + cleared film */
 int cpt_tracer_synchronize(cpt_tracer *t);
 uint32_t cpt_tracer_current_spp(const cpt_tracer *t);
