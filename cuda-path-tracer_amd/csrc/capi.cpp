@@ -422,6 +422,20 @@ int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]) {
     return CPT_OK;
 }
 
+int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches) {
+    if (!mismatches) return Fail(CPT_ERR_INVALID, "cpt_selftest_division: null argument");
+    return Guard([&] {
+        cpt::HipBuffer counter(sizeof(unsigned long long));
+        counter.Zero();
+        int rc = cpt::selftest_division(pairs, seed, counter.TypedGpuData<unsigned long long>(), nullptr);
+        if (rc != 0) return HipFail((hipError_t)rc, "selftest_division");
+        unsigned long long host = 0;
+        CPT_HIP(hipMemcpy(&host, counter.GpuData(), sizeof(host), hipMemcpyDeviceToHost));
+        *mismatches = host;
+        return CPT_OK;
+    });
+}
+
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height) {
     if (!path || !rgba) return Fail(CPT_ERR_INVALID, "cpt_write_exr: null argument");
     return WriteExrRgba(path, rgba, width, height) ? CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'");

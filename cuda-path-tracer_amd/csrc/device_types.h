@@ -39,6 +39,8 @@ struct AccelRoot {
     float bmin[3], bmax[3];
     uint32_t ref;
     uint32_t num_prims;
+    uint32_t flags;      // bit 0: some box coordinate is neither zero nor of magnitude in [2^-50, 2^50]
+    uint32_t pad;
 };
 
 struct MeshDev {

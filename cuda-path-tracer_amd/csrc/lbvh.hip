@@ -426,6 +426,17 @@ __global__ void __launch_bounds__(kBlock) k_strip_parents(uint32_t *__restrict__
 }
 
 // ---- packing into traversal records --------------------------------------------------------
+// The traversal may replace its divisions by a reciprocal-based sequence that is exact only while
+// every box coordinate is zero or of magnitude in [2^-50, 2^50]; one flag per BVH records that.
+__device__ inline bool coord_in_fast_range(float x) {
+    float a = fabsf(x);
+    return x == 0.0f || (a >= 0x1p-50f && a <= 0x1p50f);
+}
+__device__ inline bool box_in_fast_range(const Bbox &b) {
+    return coord_in_fast_range(b.pmin.x) && coord_in_fast_range(b.pmin.y) && coord_in_fast_range(b.pmin.z) && coord_in_fast_range(b.pmax.x) &&
+           coord_in_fast_range(b.pmax.y) && coord_in_fast_range(b.pmax.z);
+}
+
 __device__ inline uint32_t child_ref(uint32_t child, const AccelNode *nodes, uint32_t n, int top_level) {
     if (child < n - 1) return child;
     return kLeafBit | (top_level ? nodes[child].lc_or_id : child - (n - 1));
@@ -434,18 +445,19 @@ __device__ inline uint32_t child_ref(uint32_t child, const AccelNode *nodes, uin
 __global__ void __launch_bounds__(kBlock) k_pack_nodes(PackedNode *__restrict__ out, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes,
                                                         uint32_t n, int top_level, AccelRoot *__restrict__ root) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // root->flags was zeroed by the host before this launch; lanes only ever OR bits into it
     if (i == 0) {
-        AccelRoot r;
         Bbox b = bboxes[0];
-        r.bmin[0] = b.pmin.x; r.bmin[1] = b.pmin.y; r.bmin[2] = b.pmin.z;
-        r.bmax[0] = b.pmax.x; r.bmax[1] = b.pmax.y; r.bmax[2] = b.pmax.z;
-        r.ref = n == 1 ? (kLeafBit | (top_level ? nodes[0].lc_or_id : 0u)) : 0u;
-        r.num_prims = n;
-        *root = r;
+        root->bmin[0] = b.pmin.x; root->bmin[1] = b.pmin.y; root->bmin[2] = b.pmin.z;
+        root->bmax[0] = b.pmax.x; root->bmax[1] = b.pmax.y; root->bmax[2] = b.pmax.z;
+        root->ref = n == 1 ? (kLeafBit | (top_level ? nodes[0].lc_or_id : 0u)) : 0u;
+        root->num_prims = n;
+        if (!box_in_fast_range(b)) atomicOr(&root->flags, 1u);
     }
     if (n < 2 || i >= n - 1) return;
     AccelNode nd = nodes[i];
     Bbox l = bboxes[nd.lc_or_id], r = bboxes[nd.rc];
+    if (!box_in_fast_range(l) || !box_in_fast_range(r)) atomicOr(&root->flags, 1u);
     float4 q0 = make_float4(l.pmin.x, l.pmin.y, l.pmin.z, l.pmax.x);
     float4 q1 = make_float4(l.pmax.y, l.pmax.z, r.pmin.x, r.pmin.y);
     float4 q2 = make_float4(r.pmin.z, r.pmax.x, r.pmax.y, r.pmax.z);
@@ -593,6 +605,7 @@ int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const
               const uint32_t *indices, const V3 *positions, hipStream_t stream) {
     if (n == 0) return 0;
     int top_level = out_tris == nullptr;
+    HIP_OK(hipMemsetAsync(root, 0, sizeof(AccelRoot), stream));
     hipLaunchKernelGGL(k_pack_nodes, dim3(cdiv(n > 1 ? n - 1 : 1, kBlock)), dim3(kBlock), 0, stream, out_nodes, nodes, bboxes, n, top_level, root);
     if (!top_level) hipLaunchKernelGGL(k_pack_tris, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, out_tris, nodes, indices, positions, n);
     return (int)hipGetLastError();

@@ -17,6 +17,10 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream);
 int render_regen_resident_blocks(int device);
 
+// Compares the traversal's reciprocal-based exact division with the hardware division on at least
+// `pairs` operand pairs; adds the number of differing results to *d_mismatches (device memory).
+int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_mismatches, hipStream_t stream);
+
 // rays: device array of n * 8 floats (origin.xyz, tmin, direction.xyz, tmax).
 // inst/prim receive 0xffffffff on a miss; t receives the hit distance (or the input tmax);
 // t and uv may be null.

@@ -396,7 +396,51 @@ __global__ void __launch_bounds__(kTraceBlock) k_camera_rays(CameraDev cam, uint
     r[1] = make_float4(d.x, d.y, d.z, kRayTMax);
 }
 
+// Self-test of div_by_recip against the hardware's correctly rounded division on pseudo-random
+// operands drawn from the whole range the traversal's fast path admits (|d| in [2^-50, 2^50],
+// a zero or |a| in [2^-74, 2^51]), with extra weight on mantissas that are hard for Newton-type
+// division: all ones, powers of two, one ulp above or below a power of two.
+__device__ inline float selftest_operand(uint32_t &state, int emin, int emax) {
+    uint32_t r1 = rand_pcg(state), r2 = rand_pcg(state);
+    uint32_t mant = r1 & 0x7fffffu;
+    switch ((r2 >> 8) & 7u) {
+        case 0: mant = 0x7fffffu; break;
+        case 1: mant = 0u; break;
+        case 2: mant = 1u; break;
+        case 3: mant = 0x7ffffeu; break;
+        case 4: mant &= 0x7ff000u; break;      // short mantissas (exact quotients are common)
+        default: break;
+    }
+    int e = emin + (int)((r2 >> 16) % (uint32_t)(emax - emin + 1));
+    uint32_t bits = ((r2 & 1u) << 31) | ((uint32_t)(e + 127) << 23) | mant;
+    return __uint_as_float(bits);
+}
+
+__global__ void __launch_bounds__(256) k_div_selftest(uint32_t seed, uint32_t per_thread, unsigned long long *mismatches) {
+    uint32_t state = rand_init_tea(blockIdx.x * 256u + threadIdx.x, seed);
+    uint32_t bad = 0;
+    for (uint32_t k = 0; k < per_thread; k++) {
+        float d = selftest_operand(state, -50, 50);
+        float a = selftest_operand(state, -74, 51);
+        if ((rand_pcg(state) & 63u) == 0u) a = 0.0f;
+        float r = 1.0f / d;
+        float q = div_by_recip(a, d, r);
+        float t = a / d;
+        bad += __float_as_uint(q) != __float_as_uint(t) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 }  // namespace
+
+int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_mismatches, hipStream_t stream) {
+    const uint32_t per_thread = 4096;
+    uint64_t threads = (pairs + per_thread - 1) / per_thread;
+    uint32_t blocks = (uint32_t)((threads + 255) / 256);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_div_selftest, dim3(blocks), dim3(256), 0, stream, seed, per_thread, d_mismatches);
+    return (int)hipGetLastError();
+}
 
 int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream) {
     uint32_t tiles = ((p.width + 15) / 16) * ((p.height + 15) / 16);

@@ -2,8 +2,8 @@
 //
 // Bit-exact against the reference traversal (src/kernels/accel/accel.cuh:33-173 and
 // src/kernels/geometry/trimesh.cuh:14-43):
-//  * same slab arithmetic: six true IEEE divisions per box, compare-and-swap ordering, fmax/fmin
-//    NaN rules, hit <=> t0 <= t1 && t0 < tmax && t1 > tmin;
+//  * same slab arithmetic: six correctly rounded IEEE divisions per box, compare-and-swap
+//    ordering, fmax/fmin NaN rules, hit <=> t0 <= t1 && t0 < tmax && t1 > tmin;
 //  * same visit order: the reference pushes the left child, then the right one, and pops the
 //    right one first, testing a node's box when it is POPPED (accel.cuh:73-86).  Here both child
 //    boxes arrive with their parent's 64-byte record, so the tmax-independent part of the test
@@ -43,16 +43,59 @@ struct TraceStack {
 
 struct Hit { uint32_t inst, prim; float u, v; };
 
+// ---- correctly rounded a / d from a correctly rounded reciprocal ---------------------------------
+// With r = RN(1/d):  q0 = RN(a*r) is within 2 ulp of a/d; one residual step
+// q1 = RN(q0 + RN(a - q0*d) * r) makes it faithful (error < 1 ulp); for a faithful q1 the residual
+// a - q1*d is exact in one FMA and q2 = RN(q1 + (a - q1*d) * r) IS RN(a/d) (Markstein 1990).
+// The argument needs every intermediate to stay a normal number, which `RayFrame::fast`
+// guarantees: |d| in [2^-50, 2^50], and a = plane - origin with plane and origin each zero or of
+// magnitude in [2^-50, 2^50], so a is zero or |a| >= 2^-74 and the smallest residual, about
+// 2^-46 |a|, is still normal.  Five VALU operations instead of the ~10 of the IEEE divide
+// expansion; rays or scenes outside the range take the plain divisions.
+__device__ inline float div_by_recip(float a, float d, float r) {
+    float q = a * r;
+    float e = fmaf(-q, d, a);
+    q = fmaf(e, r, q);
+    e = fmaf(-q, d, a);
+    return fmaf(e, r, q);
+}
+
+__device__ inline bool moderate(float x) { float a = fabsf(x); return a >= 0x1p-50f && a <= 0x1p50f; }
+__device__ inline bool zero_or_moderate(float x) { return x == 0.0f || moderate(x); }
+__device__ inline bool coords_in_fast_range(float a, float b, float c) { return zero_or_moderate(a) && zero_or_moderate(b) && zero_or_moderate(c); }
+
+// A ray in one space (world or the space of the instance being traversed)
+struct RayFrame {
+    V3 o, d, r;      // origin, direction, RN(1/direction) (only meaningful when fast)
+    bool fast;
+    __device__ inline void set(V3 origin, V3 dir, bool boxes_ok) {
+        o = origin;
+        d = dir;
+        fast = boxes_ok && moderate(dir.x) && moderate(dir.y) && moderate(dir.z) && coords_in_fast_range(origin.x, origin.y, origin.z);
+        r = fast ? v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z) : v3(0.0f);
+    }
+};
+
 // accel.cuh:33-52 without the tmax clause; returns the entry distance in t0
-__device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, V3 o, V3 d, float tmin, float &t0) {
-    float x0 = (bminx - o.x) / d.x;
-    float x1 = (bmaxx - o.x) / d.x;
+__device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayFrame &f, float tmin, float &t0) {
+    float x0, x1, y0, y1, z0, z1;
+    if (f.fast) {
+        x0 = div_by_recip(bminx - f.o.x, f.d.x, f.r.x);
+        x1 = div_by_recip(bmaxx - f.o.x, f.d.x, f.r.x);
+        y0 = div_by_recip(bminy - f.o.y, f.d.y, f.r.y);
+        y1 = div_by_recip(bmaxy - f.o.y, f.d.y, f.r.y);
+        z0 = div_by_recip(bminz - f.o.z, f.d.z, f.r.z);
+        z1 = div_by_recip(bmaxz - f.o.z, f.d.z, f.r.z);
+    } else {
+        x0 = (bminx - f.o.x) / f.d.x;
+        x1 = (bmaxx - f.o.x) / f.d.x;
+        y0 = (bminy - f.o.y) / f.d.y;
+        y1 = (bmaxy - f.o.y) / f.d.y;
+        z0 = (bminz - f.o.z) / f.d.z;
+        z1 = (bmaxz - f.o.z) / f.d.z;
+    }
     float xa = x0 > x1 ? x1 : x0, xb = x0 > x1 ? x0 : x1;
-    float y0 = (bminy - o.y) / d.y;
-    float y1 = (bmaxy - o.y) / d.y;
     float ya = y0 > y1 ? y1 : y0, yb = y0 > y1 ? y0 : y1;
-    float z0 = (bminz - o.z) / d.z;
-    float z1 = (bmaxz - o.z) / d.z;
     float za = z0 > z1 ? z1 : z0, zb = z0 > z1 ? z0 : z1;
     t0 = fmaxf(xa, fmaxf(ya, za));
     float t1 = fminf(xb, fminf(yb, zb));
@@ -103,15 +146,19 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
     uint32_t cur = kNoNode;
     bool in_blas = false, found = false;
     uint32_t sp = 0, sp_base = 0, inst_id = 0;
-    V3 o = ow, d = dw;
+    RayFrame world, f;
     const PackedNode *nodes = sc.top_nodes;
     const TriRecord *tris = nullptr;
     if (active) {
         cnt.rays++;
         const AccelRoot troot = *sc.top_root;
+        world.set(ow, dw, troot.flags == 0);
         float t0;
-        if (slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], ow, dw, tmin, t0) && t0 < tmax) cur = troot.ref;
+        if (slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], world, tmin, t0) && t0 < tmax) cur = troot.ref;
+    } else {
+        world.set(ow, dw, false);
     }
+    f = world;
     for (;;) {
         const bool live = cur != kNoNode;
         const bool is_node = live && !(cur & kLeafBit);
@@ -127,8 +174,8 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
                 float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 cnt.nodes++;
                 float t0l, t0r;
-                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tmin, t0l);
-                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tmin, t0r);
+                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l);
+                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r);
                 if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
                 if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
                 else need_pop = true;
@@ -139,7 +186,7 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
                 uint32_t prim;
                 cnt.tris++;
                 need_pop = true;
-                if (tri_test(tris + (cur & ~kLeafBit), o, d, tmin, tmax, t, bv, bw, prim)) {
+                if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, tmin, tmax, t, bv, bw, prim)) {
                     found = true;
                     if (ANY) {
                         need_pop = false;
@@ -155,23 +202,22 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
                 inst_id = cur & ~kLeafBit;
                 const InstanceDev &in = sc.instances[inst_id];
                 M4 inv = in.transform_inv;
-                o = xyz(mul(inv, v4(ow, 1.0f)));
-                d = xyz(mul(inv, v4(dw, 0.0f)));
                 const MeshDev &m = sc.meshes[in.mesh];
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
+                f.set(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
-                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], o, d, tmin, t0) && t0 < tmax) cur = r.ref;
+                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, tmin, t0) && t0 < tmax) cur = r.ref;
                 else need_pop = true;
             }
         }
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
-                if (in_blas && sp == sp_base) { in_blas = false; o = ow; d = dw; nodes = sc.top_nodes; }
+                if (in_blas && sp == sp_base) { in_blas = false; f = world; nodes = sc.top_nodes; }
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);

@@ -149,6 +149,11 @@ int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
 
+/* Device self-test: the traversal divides by a ray direction through a reciprocal-based sequence
+ * that must equal the correctly rounded quotient bit for bit; this runs at least `pairs` operand
+ * pairs from its admissible range through both and reports how many differ (expected: 0). */
+int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches);
+
 /* Standalone OpenEXR writer used by Film::SaveTo (src/pathtracer/film.cpp:61-68). */
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height);
 

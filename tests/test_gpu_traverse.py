@@ -130,3 +130,35 @@ def test_counters_and_edge_cases(cpt):
     bad[:, 7] = 1e30
     bad[0, 4:7] = np.nan
     assert_same_hits(tr, osc, bad)
+
+
+def test_reciprocal_division_is_correctly_rounded(cpt):
+    """The slab test divides through RN(1/d) plus two FMA residual steps; over 2^36 operand pairs
+    from its admissible range (including all-ones / power-of-two mantissas) it must equal the
+    hardware's IEEE division bit for bit."""
+    import ctypes as C
+    for seed in (1, 2):
+        bad = C.c_uint64(123)
+        cpt.check(cpt.lib.cpt_selftest_division(1 << 35, seed, C.byref(bad)))
+        assert bad.value == 0
+
+
+def test_scenes_outside_the_fast_division_range(cpt):
+    """A box coordinate of 1e-20 (nonzero, below the 2^-50 bound under which the reciprocal
+    sequence is proven exact) must switch the floor's bottom-level structure and the top-level
+    structure to plain divisions; results still match the oracle bit for bit."""
+    objs, cam = cornell(glass=False)
+    odd = [dict(o) for o in objs]
+    floor = odd[1]["positions"].copy()
+    floor[:, 1] = np.float32(1e-20)
+    odd[1]["positions"] = floor
+    osc = OracleScene(odd, cam)
+    sc, tr = gpu_scene(cpt, odd, cam)
+    inst, _ = assert_same_hits(tr, osc, osc.camera_rays(384, 384, 1))
+    assert (inst == 1).any()                            # the floor is seen
+    assert_same_hits(tr, osc, interior_rays(100000, 21, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32)))
+    # rays whose origin has a tiny nonzero component take the plain divisions as well
+    rays = interior_rays(50000, 22, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32))
+    rays[:, 1] = np.float32(3e-19)
+    sc2, tr2 = gpu_scene(cpt, objs, cam)
+    assert_same_hits(tr2, OracleScene(objs, cam), rays)
