@@ -131,41 +131,52 @@ __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, fl
 
 constexpr uint32_t kNoNode = 0xffffffffu;
 
-// Closest hit (ANY = false; AccelTop::Intersect, accel.cuh:124-150) or any hit (ANY = true;
-// AccelTop::Occlude, accel.cuh:152-173).  tmax is updated to the hit distance on closest hits.
+// Traversal state of one lane: where it stands (`cur`: internal node, triangle slot, instance
+// leaf, or kNoNode when the ray is finished), its stack window and the ray in world and instance
+// space.  Closest hit (ANY = false) is AccelTop::Intersect (accel.cuh:124-150), any hit
+// (ANY = true) is AccelTop::Occlude (accel.cuh:152-173).
 //
-// All lanes of the wave that reach this call run it together (`active` = false for lanes with
-// nothing to trace).  Each lane is in one of three states -- at an internal node, at a triangle,
-// at an instance leaf -- and every trip of the loop the wave votes (ballot + popcount) for the
-// state most lanes are in and executes only that step; the other lanes wait with their state
-// intact.  A lane's own sequence of box tests, triangle tests and stack operations is exactly the
-// sequential one, so results do not depend on the vote, but the expensive node step always runs
-// with as many lanes as possible instead of being serialised with the other two every trip.
-template <bool ANY>
-__device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
+// vote_step() is one trip of the traversal loop for the whole wave: each live lane is at an
+// internal node, at a triangle or at an instance leaf; the wave votes (three ballots + popcounts)
+// for the state most lanes are in and executes only that step, the other lanes keep their state
+// and wait.  A lane's own sequence of box tests, triangle tests and stack operations is exactly
+// the sequential one, so results do not depend on the vote, but the expensive node step always
+// runs with as many lanes as possible instead of being serialised with the other two every trip.
+struct Traversal {
     uint32_t cur = kNoNode;
-    bool in_blas = false, found = false;
     uint32_t sp = 0, sp_base = 0, inst_id = 0;
+    bool in_blas = false, found = false;
+    float tmin = 0.0f, tmax = 0.0f;
     RayFrame world, f;
-    const PackedNode *nodes = sc.top_nodes;
+    const PackedNode *nodes = nullptr;
     const TriRecord *tris = nullptr;
-    if (active) {
+    Hit hit;
+
+    // tests the top-level root box; afterwards live() tells whether there is anything to walk
+    __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float tmin_, float tmax_, LaneCounters &cnt) {
         cnt.rays++;
+        cur = kNoNode;
+        sp = 0; sp_base = 0;
+        in_blas = false; found = false;
+        tmin = tmin_; tmax = tmax_;
+        nodes = sc.top_nodes;
         const AccelRoot troot = *sc.top_root;
         world.set(ow, dw, troot.flags == 0);
+        f = world;
         float t0;
         if (slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], world, tmin, t0) && t0 < tmax) cur = troot.ref;
-    } else {
-        world.set(ow, dw, false);
     }
-    f = world;
-    for (;;) {
-        const bool live = cur != kNoNode;
-        const bool is_node = live && !(cur & kLeafBit);
-        const bool is_tri = live && (cur & kLeafBit) && in_blas;
-        const bool is_inst = live && (cur & kLeafBit) && !in_blas;
+    __device__ inline bool live() const { return cur != kNoNode; }
+
+    // returns false when no lane of the wave that called it has work left
+    template <bool ANY>
+    __device__ inline bool vote_step(const SceneDev &sc, TraceStack &st, LaneCounters &cnt) {
+        const bool alive = cur != kNoNode;
+        const bool is_node = alive && !(cur & kLeafBit);
+        const bool is_tri = alive && (cur & kLeafBit) && in_blas;
+        const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
         const unsigned long long mn = __ballot(is_node), mt = __ballot(is_tri), mi = __ballot(is_inst);
-        if ((mn | mt | mi) == 0ull) break;
+        if ((mn | mt | mi) == 0ull) return false;
         const int cn = __popcll(mn), ct = __popcll(mt), ci = __popcll(mi);
         bool need_pop = false;
         if (cn >= ct && cn >= ci) {
@@ -206,7 +217,7 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
-                f.set(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
+                f.set(xyz(mul(inv, v4(world.o, 1.0f))), xyz(mul(inv, v4(world.d, 0.0f))), r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
@@ -224,8 +235,20 @@ __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, floa
                 if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
             }
         }
+        return true;
     }
-    return found;
+};
+
+// One ray per lane, all lanes of the wave that reach the call together (`active` = false for
+// lanes with nothing to trace); returns when every lane's ray is finished.  tmax is updated to
+// the hit distance on closest hits.
+template <bool ANY>
+__device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
+    Traversal t;
+    if (active) t.begin(sc, ow, dw, tmin, tmax, cnt);
+    while (t.vote_step<ANY>(sc, st, cnt)) {}
+    if (!ANY && t.found) { hit = t.hit; tmax = t.tmax; }
+    return t.found;
 }
 
 }  // namespace cpt
