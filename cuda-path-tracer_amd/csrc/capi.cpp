@@ -81,7 +81,9 @@ int cpt_free(void *d_ptr) {
     return e == hipSuccess ? CPT_OK : HipFail(e, "hipFree");
 }
 int cpt_memcpy_h2d(void *d_dst, const void *src, size_t bytes) {
+    // complete on return, also as seen from non-blocking streams (kernels of a tracer run on one)
     hipError_t e = hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemcpy H2D");
 }
 int cpt_memcpy_d2h(void *dst, const void *d_src, size_t bytes) {
@@ -90,6 +92,7 @@ int cpt_memcpy_d2h(void *dst, const void *d_src, size_t bytes) {
 }
 int cpt_memset(void *d_dst, int value, size_t bytes) {
     hipError_t e = hipMemset(d_dst, value, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemset");
 }
 int cpt_synchronize(void) {
@@ -303,7 +306,7 @@ int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth) { TRACER_OR_FAIL(t); 
 int cpt_tracer_set_channel(cpt_tracer *t, int channel) { TRACER_OR_FAIL(t); t->tracer->SetChannel(channel); return CPT_OK; }
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
     TRACER_OR_FAIL(t);
-    if (mode != 0 && mode != 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0 or 1");
+    if (mode < 0 || mode > 2) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0, 1 or 2");
     t->tracer->SetIntegrator(mode);
     return CPT_OK;
 }
@@ -336,7 +339,7 @@ int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_co
 
 float *cpt_tracer_film_device_ptr(cpt_tracer *t) {
     if (!t) return nullptr;
-    try { return t->film->DeviceMap(); } catch (const std::exception &e) { Fail(CPT_ERR_DEVICE, e.what()); return nullptr; }
+    try { return t->film->DeviceMap(t->tracer->Stream()); } catch (const std::exception &e) { Fail(CPT_ERR_DEVICE, e.what()); return nullptr; }
 }
 int cpt_tracer_film_read(cpt_tracer *t, float *rgba) {
     TRACER_OR_FAIL(t);

@@ -16,24 +16,26 @@ void Film::Resize(uint32_t width, uint32_t height) {
     if (width_ != width || height_ != height) Init(width, height);
 }
 
-float *Film::DeviceMap() {
+float *Film::DeviceMap(hipStream_t stream) {
     if (!allocated_) {
         buffer_.Allocate((size_t)width_ * height_ * 16);
         // the running mean multiplies the previous value by 0 at the first sample: a NaN left in
-        // fresh memory would survive that, so the buffer starts from zeros
-        CPT_HIP(hipMemset(buffer_.GpuData(), 0, (size_t)width_ * height_ * 16));
+        // fresh memory would survive that, so the buffer starts from zeros.  The clear is finished
+        // before this returns, whichever stream the caller renders on.
+        CPT_HIP(hipMemsetAsync(buffer_.GpuData(), 0, (size_t)width_ * height_ * 16, stream));
+        CPT_HIP(hipStreamSynchronize(stream));
         allocated_ = true;
     }
     return buffer_.TypedGpuData<float>();
 }
 
 void Film::Clear(hipStream_t stream) {
-    float *p = DeviceMap();
+    float *p = DeviceMap(stream);
     CPT_HIP(hipMemsetAsync(p, 0, (size_t)width_ * height_ * 16, stream));
 }
 
 void Film::ReadBack(float *dst, hipStream_t stream) {
-    float *p = DeviceMap();
+    float *p = DeviceMap(stream);
     CPT_HIP(hipMemcpyAsync(dst, p, (size_t)width_ * height_ * 16, hipMemcpyDeviceToHost, stream));
     CPT_HIP(hipStreamSynchronize(stream));
 }

@@ -16,7 +16,8 @@ public:
     void Resize(uint32_t width, uint32_t height);
 
     // Device pointer to the accumulation buffer (the reference's CudaMap / CudaUnmap pair).
-    float *DeviceMap();
+    // `stream`: the stream whose kernels will write the buffer; the first-use clear is ordered on it
+    float *DeviceMap(hipStream_t stream = nullptr);
     void DeviceUnmap() {}
     void Clear(hipStream_t stream = nullptr);
 

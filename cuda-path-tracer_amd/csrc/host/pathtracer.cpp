@@ -246,7 +246,7 @@ void PathTracer::Update() {
     }
     ++curr_spp_;
     cpt::RenderParams p;
-    p.output = film_.DeviceMap();
+    p.output = film_.DeviceMap(stream_);
     p.width = film_.Width();
     p.height = film_.Height();
     p.spp = curr_spp_;
@@ -257,7 +257,43 @@ void PathTracer::Update() {
     film_.DeviceUnmap();
 }
 
+void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
+    size_t slots = cpt::wavefront_slots(p.width, p.height);
+    if (wf_.capacity != slots) {
+        wf_state_.Allocate(slots * 8 * sizeof(float4));
+        wf_queues_.Allocate((slots * 3 + 8) * sizeof(uint32_t));
+        float4 *s = wf_state_.TypedGpuData<float4>();
+        wf_.ray_o = s; wf_.ray_d = s + slots; wf_.thr = s + 2 * slots; wf_.col = s + 3 * slots;
+        wf_.hit = s + 4 * slots; wf_.sh_o = s + 5 * slots; wf_.sh_d = s + 6 * slots; wf_.pending = s + 7 * slots;
+        uint32_t *q = wf_queues_.TypedGpuData<uint32_t>();
+        wf_.counts = q;
+        wf_.queue[0] = q + 8; wf_.queue[1] = q + 8 + slots; wf_.shadow_queue = q + 8 + 2 * slots;
+        wf_.capacity = (uint32_t)slots;
+        int device = 0;
+        CPT_HIP(hipGetDevice(&device));
+        wf_resident_blocks_ = cpt::wavefront_resident_blocks(device);
+    }
+    rc_check(cpt::wavefront_begin_sample(scene_dev_, p, wf_, stream_), "wavefront generate");
+    if (p.max_depth != 0xffffffffu && p.max_depth <= 64) {
+        for (uint32_t b = 0; b <= p.max_depth; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b & 1u, (uint32_t)wf_resident_blocks_, stream_), "wavefront bounce");
+        return;
+    }
+    // unbounded depth: Russian roulette ends every path; look at the live count every few bounces
+    uint32_t bounce = 0;
+    for (;;) {
+        for (int k = 0; k < 4; k++, bounce++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, bounce & 1u, (uint32_t)wf_resident_blocks_, stream_), "wavefront bounce");
+        uint32_t live = 0;
+        CPT_HIP(hipMemcpyAsync(&live, wf_.counts + (bounce & 1u), sizeof(live), hipMemcpyDeviceToHost, stream_));
+        CPT_HIP(hipStreamSynchronize(stream_));
+        if (live == 0 || bounce > p.max_depth || bounce >= (1u << 16)) break;
+    }
+}
+
 void PathTracer::LaunchSample(const cpt::RenderParams &p) {
+    if (integrator_ == 2) {
+        LaunchWavefront(p);
+        return;
+    }
     if (integrator_ == 1) {
         rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
         return;
@@ -277,7 +313,7 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
     cpt::RenderParams p;
-    p.output = output ? output : film_.DeviceMap();
+    p.output = output ? output : film_.DeviceMap(stream_);
     p.width = output ? width : film_.Width();
     p.height = output ? height : film_.Height();
     p.max_depth = static_cast<uint32_t>(max_depth_);

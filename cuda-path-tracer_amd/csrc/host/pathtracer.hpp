@@ -11,6 +11,7 @@
 
 #include "../device_types.h"
 #include "../lbvh.h"
+#include "../wavefront.h"
 #include "buffer.hpp"
 #include "film.hpp"
 #include "scene.hpp"
@@ -29,7 +30,8 @@ public:
 
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
-    // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel
+    // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
+    // 2: wavefront (ray queues in HBM, one kernel sequence per bounce)
     void SetIntegrator(int mode) { integrator_ = mode; }
     void Synchronize();
     uint32_t CurrentSpp() const { return curr_spp_; }
@@ -84,6 +86,10 @@ private:
     int resident_blocks_ = 0;
     cpt::HipBuffer queue_;
     void LaunchSample(const cpt::RenderParams &p);
+    void LaunchWavefront(const cpt::RenderParams &p);
+    cpt::HipBuffer wf_state_, wf_queues_;
+    cpt::WavefrontBuffers wf_{};
+    int wf_resident_blocks_ = 0;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 
     cpt::BuildWorkspace workspace_;

@@ -5,58 +5,11 @@
 
 #include <hip/hip_runtime.h>
 
-#include "shading.h"
-#include "trace.h"
+#include "integrate.h"
 
 namespace cpt {
 
 namespace {
-
-struct Surface { Vertex vertex; BsdfDev bsdf; int32_t light; };
-
-// src/kernels/scene/instance.cuh:19-26
-__device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit, LaneCounters &cnt) {
-    cnt.shades++;
-    const InstanceDev &in = sc.instances[hit.inst];
-    const MeshDev &m = sc.meshes[in.mesh];
-    Surface s;
-    s.vertex = get_vertex(m, hit.prim, hit.u, hit.v);
-    M4 tr = in.transform;
-    vertex_transform_pdf(s.vertex, tr);
-    s.vertex.position = xyz(mul(tr, v4(s.vertex.position, 1.0f)));
-    s.vertex.normal = xyz(normalize4(mul(in.transform_it, v4(s.vertex.normal, 0.0f))));   // 4-component normalise, as the reference writes it
-    s.bsdf = sc.materials[in.material];
-    s.light = in.light;
-    return s;
-}
-
-struct LightSample { V3 dir; float pdf; V3 weight; float dist; };
-
-// src/kernels/geometry/geometry.cuh:27-39 + src/kernels/light/geometry.cuh:17-30
-__device__ inline LightSample light_sample(const SceneDev &sc, uint32_t inst_id, V3 pos, V2 rand) {
-    const InstanceDev &in = sc.instances[inst_id];
-    const MeshDev &m = sc.meshes[in.mesh];
-    Vertex vert = sample_vertex(m, rand);
-    M4 tr = in.transform;
-    vertex_transform_pdf(vert, tr);
-    vert.position = xyz(mul(tr, v4(vert.position, 1.0f)));
-    vert.normal = xyz(normalize4(mul(in.transform_it, v4(vert.normal, 0.0f))));
-    V3 vec = vert.position - pos;
-    float dist_sqr = dot(vec, vec);
-    float dist = sqrtf(dist_sqr);
-    V3 dir = vec / dist;
-    LightSample ls;
-    ls.dir = dir;
-    ls.dist = dist;
-    float cos_theta = dot(-dir, vert.normal);
-    ls.pdf = cos_theta > 0.0f ? vert.pdf * dist_sqr / cos_theta : 0.0f;
-    ls.weight = sc.materials[in.material].emission / ls.pdf;
-    return ls;
-}
-
-constexpr float kRayTMin = 0.0001f;          // src/kernels/basic/ray.cuh:8-10
-constexpr float kRayTMax = 3.402823466e+38f;
-constexpr float kShadowRayEps = 0.001f;
 
 // src/kernels/integrator/path.cu:9-83
 __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, TraceStack &st, LaneCounters &cnt) {
@@ -120,25 +73,6 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
     return color;
 }
 
-__device__ inline void flush_counters(const SceneDev &sc, const LaneCounters &cnt, uint32_t paths, unsigned long long *block_cnt) {
-    if (!sc.counters) return;
-    if (threadIdx.x < 5) block_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    atomicAdd(&block_cnt[0], (unsigned long long)cnt.rays);
-    atomicAdd(&block_cnt[1], (unsigned long long)cnt.nodes);
-    atomicAdd(&block_cnt[2], (unsigned long long)cnt.tris);
-    atomicAdd(&block_cnt[3], (unsigned long long)paths);
-    atomicAdd(&block_cnt[4], (unsigned long long)cnt.shades);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&sc.counters->rays, block_cnt[0]);
-        atomicAdd(&sc.counters->node_visits, block_cnt[1]);
-        atomicAdd(&sc.counters->tri_tests, block_cnt[2]);
-        atomicAdd(&sc.counters->paths, block_cnt[3]);
-        atomicAdd(&sc.counters->shades, block_cnt[4]);
-    }
-}
-
 // Workgroups are dealt to the 8 XCDs round robin; give each XCD one contiguous band of tiles so
 // that neighbouring tiles, which walk the same part of the BVH, share an L2.
 __device__ inline uint32_t xcd_band_remap(uint32_t b, uint32_t nb) {
@@ -166,18 +100,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
         V3 ro, rd;
         pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
         V3 color = trace_path(sc, ro, rd, sampler, p.max_depth, p.channel, st, cnt);
-        if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
-        float4 *out = reinterpret_cast<float4 *>(p.output) + pixel_index;
-        float4 prev = *out;
-        float4 res;
-        if (p.sum_mode) {
-            res = make_float4(prev.x + color.x, prev.y + color.y, prev.z + color.z, prev.w + 1.0f);
-        } else {
-            float a = 1.0f / (float)p.spp;      // glm::mix(prev, new, a) = prev * (1 - a) + new * a  (path.cu:102-104)
-            res = make_float4(prev.x * (1.0f - a) + color.x * a, prev.y * (1.0f - a) + color.y * a, prev.z * (1.0f - a) + color.z * a,
-                              prev.w * (1.0f - a) + 1.0f * a);
-        }
-        *out = res;
+        film_accumulate(p, pixel_index, color);
     }
     flush_counters(sc, cnt, active ? 1u : 0u, s_cnt);
 }
@@ -326,18 +249,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
 
         // ---- film (path.cu:99-104)
         if (alive && finish) {
-            V3 c = color;
-            if (isnan(c.x) || isnan(c.y) || isnan(c.z) || isinf(c.x) || isinf(c.y) || isinf(c.z)) c = v3(0.0f);
-            float4 *out = reinterpret_cast<float4 *>(p.output) + pixel_index;
-            float4 prev = *out;
-            float4 res;
-            if (p.sum_mode) {
-                res = make_float4(prev.x + c.x, prev.y + c.y, prev.z + c.z, prev.w + 1.0f);
-            } else {
-                float a = 1.0f / (float)p.spp;
-                res = make_float4(prev.x * (1.0f - a) + c.x * a, prev.y * (1.0f - a) + c.y * a, prev.z * (1.0f - a) + c.z * a, prev.w * (1.0f - a) + 1.0f * a);
-            }
-            *out = res;
+            film_accumulate(p, pixel_index, color);
             alive = false;
         }
     }

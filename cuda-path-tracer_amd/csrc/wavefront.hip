@@ -1,0 +1,293 @@
+// Wavefront (ray-queue) variant of the bounce loop for gfx950.
+//
+// The path state lives in HBM (structure of arrays, 16-byte fields) and one sample per pixel is
+// rendered by a short sequence of kernels per bounce:
+//     generate -> [ extend -> shade -> shadow -> reset ] x (max_depth + 1)
+// extend / shadow are persistent traversal kernels: a lane whose ray is finished takes the next
+// ray from the queue INSIDE the traversal loop (ballot + popcount prefix over idle lanes), so the
+// wave-voted node step keeps most of its 64 lanes busy however uneven the rays are.  shade runs
+// the integrator between two rays of a path with the reference's operation and random-draw order
+// (src/kernels/integrator/path.cu:9-83), so a path computes bit for bit what it computes in the
+// megakernels; only the order in which different paths are processed changes.
+#include "wavefront.h"
+
+#include <hip/hip_runtime.h>
+
+#include "integrate.h"
+
+namespace cpt {
+
+namespace {
+
+constexpr uint32_t kPrimaryBit = 0x80000000u;
+constexpr uint32_t kSpecularBit = 0x40000000u;
+constexpr uint32_t kPixelMask = 0x3fffffffu;
+constexpr uint32_t kFetchBatch = 256;      // queue entries a wave reserves at a time
+constexpr int kRefillIdleLanes = 16;       // refill as soon as this many lanes of a wave are idle
+
+// appends one entry per lane with flag set; one atomic per wave
+__device__ inline void queue_append(uint32_t *queue, uint32_t *count, bool flag, uint32_t value) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, (int)leader, 64);
+    if (flag) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+// one lane per pixel slot (8x8 tiles): camera ray + fresh path state, src/kernels/integrator/path.cu:86-96
+__global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t tiles_x = (p.width + 7) / 8;
+    const uint32_t tile = slot >> 6, k = slot & 63u;
+    const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+    const bool valid = slot < wb.capacity && px < p.width && py < p.height;
+    if (valid) {
+        Sampler sampler;
+        uint32_t pixel_index;
+        V3 ro, rd;
+        pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
+        wb.ray_o[slot] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(pixel_index | kPrimaryBit));
+        wb.ray_d[slot] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(sampler.state));
+        wb.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
+        wb.col[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    queue_append(wb.queue[0], &wb.counts[0], valid, slot);
+    if (sc.counters && valid) {
+        const unsigned long long m = __ballot(true);
+        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&sc.counters->paths, (unsigned long long)__popcll(m));
+    }
+}
+
+// Persistent traversal over a queue of path ids.  ANY = false: closest hit of the path's current
+// ray, result to wb.hit.  ANY = true: the path's shadow ray; an unoccluded ray adds the pending
+// light contribution to the path's colour, and a path that was only waiting for this ray is
+// written to the film.
+template <bool ANY>
+__global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t parity) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t *queue = ANY ? wb.shadow_queue : wb.queue[parity];
+    const uint32_t total = ANY ? wb.counts[2] : wb.counts[parity];
+    uint32_t *cursor = &wb.counts[ANY ? 4 : 3];
+
+    uint32_t next = 0, end = 0;
+    bool exhausted = total == 0;
+    Traversal t;
+    bool have = false;
+    uint32_t path = 0;
+    for (;;) {
+        unsigned long long idle = __ballot(!have);
+        if (!exhausted && (__popcll(idle) >= kRefillIdleLanes || idle == ~0ull)) {
+            while (idle != 0ull && !exhausted) {
+                if (next >= end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(cursor, kFetchBatch);
+                    b = __shfl(b, 0, 64);
+                    if (b >= total) { exhausted = true; break; }
+                    next = b;
+                    end = min(b + kFetchBatch, total);
+                }
+                const uint32_t rank = __popcll(idle & lt_mask);
+                const uint32_t take = min((uint32_t)__popcll(idle), end - next);
+                if (!have && rank < take) {
+                    path = queue[next + rank];
+                    if (ANY) {
+                        float4 o = wb.sh_o[path], d = wb.sh_d[path];
+                        t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, o.w, cnt);
+                    } else {
+                        float4 o = wb.ray_o[path], d = wb.ray_d[path];
+                        t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, kRayTMax, cnt);
+                    }
+                    have = true;
+                }
+                next += take;
+                idle = __ballot(!have);
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+        t.vote_step<ANY>(sc, st, cnt);
+        if (have && !t.live()) {
+            if (ANY) {
+                float4 c = wb.col[path];
+                if (!t.found) {
+                    float4 pend = wb.pending[path];
+                    c.x = c.x + pend.x; c.y = c.y + pend.y; c.z = c.z + pend.z;
+                    wb.col[path] = c;
+                }
+                if (__float_as_uint(wb.sh_d[path].w) != 0u) film_accumulate(p, __float_as_uint(wb.ray_o[path].w) & kPixelMask, v3(c.x, c.y, c.z));
+            } else {
+                wb.hit[path] = t.found ? make_float4(__uint_as_float(t.hit.inst), __uint_as_float(t.hit.prim), t.hit.u, t.hit.v)
+                                       : make_float4(__uint_as_float(0xffffffffu), 0.0f, 0.0f, 0.0f);
+            }
+            have = false;
+        }
+    }
+    flush_counters(sc, cnt, 0u, s_cnt);
+}
+
+// Everything the integrator does between two rays of one path (path.cu:12-80 in the order the
+// statements run for one path): primary-hit special cases, emitter hit with MIS, Russian roulette,
+// depth test, light sample (shadow ray + pending contribution), BSDF sample (next ray).
+__global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t parity) {
+    __shared__ unsigned long long s_cnt[5];
+    LaneCounters cnt;
+    const uint32_t total = wb.counts[parity];
+    const uint32_t *queue = wb.queue[parity];
+    uint32_t *next_queue = wb.queue[parity ^ 1u];
+    uint32_t *next_count = &wb.counts[parity ^ 1u];
+    const uint32_t rounds = (total + gridDim.x * 256 - 1) / (gridDim.x * 256);
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const bool valid = i < total;
+        bool cont = false, need_shadow = false;
+        uint32_t path = 0;
+        if (valid) {
+            path = queue[i];
+            float4 fo = wb.ray_o[path], fd = wb.ray_d[path], ft = wb.thr[path], fc = wb.col[path], fh = wb.hit[path];
+            uint32_t tag = __float_as_uint(fo.w);
+            const uint32_t pixel_index = tag & kPixelMask;
+            bool primary = (tag & kPrimaryBit) != 0, last_specular = (tag & kSpecularBit) != 0;
+            Sampler sampler{__float_as_uint(fd.w)};
+            V3 ro = v3(fo.x, fo.y, fo.z), rd = v3(fd.x, fd.y, fd.z);
+            V3 throughput = v3(ft.x, ft.y, ft.z), color = v3(fc.x, fc.y, fc.z);
+            uint32_t depth = __float_as_uint(ft.w);
+            float last_pdf = fc.w;
+            bool finish = false;
+            V3 contrib = v3(0.0f), ldir = v3(0.0f), pos = v3(0.0f);
+            float smax = 0.0f;
+
+            Hit hit;
+            hit.inst = __float_as_uint(fh.x); hit.prim = __float_as_uint(fh.y); hit.u = fh.z; hit.v = fh.w;
+            if (hit.inst == 0xffffffffu) {
+                finish = true;
+            } else {
+                Surface surface = shading_surface(sc, hit, cnt);
+                if (primary) {
+                    primary = false;
+                    if (p.channel == 1) { color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
+                    else { color = surface.bsdf.emission; if (!is_zero(color)) finish = true; }
+                } else if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
+                    float mis_weight = 1.0f;
+                    if (!last_specular) {
+                        float light_pdf = surface.vertex.pdf * path_to_solid_angle_jacobian(ro, surface.vertex.position, surface.vertex.normal) *
+                                          sc.light_pick_pdf;
+                        mis_weight = power_heuristic(last_pdf, light_pdf);
+                    }
+                    color = color + throughput * mis_weight * surface.bsdf.emission;
+                    finish = true;
+                } else {
+                    float rr_prop = gmin(gmax(luminance(throughput), 0.01f), 0.95f);
+                    if (sampler.next1d() > rr_prop) finish = true;
+                    else { throughput = throughput / rr_prop; depth++; }
+                }
+                if (!finish && !(depth < p.max_depth)) finish = true;
+                if (!finish) {
+                    pos = surface.vertex.position;
+                    Frame frame = Frame::from_normal(surface.vertex.normal);
+                    V3 wo = frame.to_local(-rd);
+                    if (!bsdf_is_delta(surface.bsdf)) {
+                        float r1 = sampler.next1d();
+                        uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
+                        V2 r2 = sampler.next2d();
+                        LightSample ls = light_sample(sc, sc.lights[index], pos, r2);
+                        ls.pdf *= sc.light_pick_pdf;
+                        ls.weight = ls.weight / sc.light_pick_pdf;
+                        if (ls.pdf > 0.0f) {
+                            need_shadow = true;
+                            ldir = ls.dir;
+                            smax = ls.dist - kShadowRayEps;
+                            V3 wi = frame.to_local(ls.dir);
+                            float bp = bsdf_pdf(surface.bsdf, wo, wi);
+                            float mis_weight = power_heuristic(ls.pdf, bp);
+                            contrib = throughput * mis_weight * ls.weight * bsdf_eval(surface.bsdf, wo, wi);
+                        }
+                    }
+                    float b1 = sampler.next1d();
+                    V2 b2 = sampler.next2d();
+                    BsdfSample bs = bsdf_sample(surface.bsdf, wo, b1, b2);
+                    if (bs.pdf == 0.0f) {
+                        finish = true;
+                    } else {
+                        throughput = throughput * bs.weight;
+                        ro = pos;
+                        rd = frame.to_world(bs.wi);
+                        last_pdf = bs.pdf;
+                        last_specular = bs.lobe == kLobeSpecular;
+                    }
+                }
+            }
+            cont = !finish;
+            tag = pixel_index | (primary ? kPrimaryBit : 0u) | (last_specular ? kSpecularBit : 0u);
+            if (need_shadow) {
+                wb.sh_o[path] = make_float4(pos.x, pos.y, pos.z, smax);
+                wb.sh_d[path] = make_float4(ldir.x, ldir.y, ldir.z, __uint_as_float(finish ? 1u : 0u));
+                wb.pending[path] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+            }
+            if (cont || need_shadow) {
+                wb.ray_o[path] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(tag));
+                wb.col[path] = make_float4(color.x, color.y, color.z, last_pdf);
+            }
+            if (cont) {
+                wb.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(sampler.state));
+                wb.thr[path] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(depth));
+            }
+            if (finish && !need_shadow) film_accumulate(p, pixel_index, color);
+        }
+        queue_append(next_queue, next_count, cont, path);
+        queue_append(wb.shadow_queue, &wb.counts[2], need_shadow, path);
+    }
+    flush_counters(sc, cnt, 0u, s_cnt);
+}
+
+// end of one bounce: the queue just consumed and the shadow queue become empty, cursors rewind
+__global__ void k_wf_reset(WavefrontBuffers wb, uint32_t parity) {
+    if (threadIdx.x == 0) {
+        wb.counts[parity] = 0;
+        wb.counts[2] = 0;
+        wb.counts[3] = 0;
+        wb.counts[4] = 0;
+    }
+}
+
+}  // namespace
+
+size_t wavefront_slots(uint32_t width, uint32_t height) { return (size_t)((width + 7) / 8) * ((height + 7) / 8) * 64; }
+
+int wavefront_resident_blocks(int device) {
+    int a = 0, b = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false>, kTraceBlock, 0) != hipSuccess || a < 1) a = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true>, kTraceBlock, 0) != hipSuccess || b < 1) b = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return (a < b ? a : b) * cus;
+}
+
+int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(wb.counts, 0, 8 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    uint32_t blocks = (wb.capacity + 255) / 256;
+    hipLaunchKernelGGL(k_wf_generate, dim3(blocks), dim3(256), 0, stream, sc, p, wb);
+    return (int)hipGetLastError();
+}
+
+int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t parity, uint32_t resident_blocks, hipStream_t stream) {
+    uint32_t want = (wb.capacity + kFetchBatch * (kTraceBlock / 64) - 1) / (kFetchBatch * (kTraceBlock / 64));
+    uint32_t blocks = want < resident_blocks ? want : resident_blocks;
+    if (blocks == 0) blocks = 1;
+    uint32_t shade_blocks = (wb.capacity + 255) / 256;
+    if (shade_blocks > 4 * resident_blocks) shade_blocks = 4 * resident_blocks;
+    hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb, parity);
+    hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, parity);
+    hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb, parity);
+    hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, wb, parity);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cpt

@@ -102,7 +102,9 @@ int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth);         /* -1 = unbo
 int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour, 1 shading normal */
 /* Bounce-loop kernel: 0 = persistent megakernel whose lanes pick up a new pixel as soon as their
  * path ends (default); 1 = one lane per pixel for the whole launch, the structure of the
- * reference's RenderKernel (src/kernels/integrator/path.cu:85-105).  Same image either way. */
+ * reference's RenderKernel (src/kernels/integrator/path.cu:85-105); 2 = wavefront: path state and
+ * ray queues in device memory, extend / shade / shadow kernels per bounce, traversal kernels that
+ * refill idle lanes from the queue.  Same image in all three. */
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
 int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */

@@ -136,16 +136,38 @@ def test_cli_renders_an_exr(cpt, tmp_path):
     compare(img, ref)
 
 
-def test_both_kernels_give_the_same_image_bit_for_bit(cpt):
-    """The persistent lane-regenerating kernel and the one-lane-per-pixel kernel run the same
-    per-path operation sequence, so their films must be identical, not merely close."""
+@pytest.mark.parametrize("depth", [8, 0, 1, -1])
+def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
+    """The persistent lane-regenerating megakernel (0), the one-lane-per-pixel megakernel (1) and
+    the wavefront ray-queue variant (2) run the same per-path operation sequence, so their films
+    must be identical, not merely close; so must their ray counts."""
     objs, cam = cornell(glass=True)
-    imgs = []
-    for mode in (0, 1):
-        sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=8)     # not a multiple of the 8x8 tiles
+    imgs, rays = [], []
+    for mode in (0, 1, 2):
+        sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=depth)     # not a multiple of the 8x8 tiles
         tr.set_integrator(mode)
         tr.update(6)
         imgs.append(tr.film())
         c = tr.counters()
         assert c["paths"] == 200 * 120 * 6
+        rays.append((c["rays"], c["node_visits"], c["tri_tests"], c["shades"]))
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[2].view(np.uint32))
+    assert rays[0] == rays[1] == rays[2]
+
+
+def test_wavefront_sum_mode_and_normal_channel(cpt):
+    objs, cam = cornell(glass=False)
+    out = []
+    for mode in (0, 2):
+        sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=4)
+        tr.set_integrator(mode)
+        buf = cpt.DeviceArray((64, 64, 4), np.float32); buf.zero()
+        tr.render_samples(3, 5, True, buf.ptr, 64, 64)
+        tr.synchronize()
+        a = buf.to_host()
+        tr.set_channel(1)
+        tr.update(1)
+        out.append((a, tr.film()))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
