@@ -65,6 +65,7 @@ _sig("cpt_tracer_destroy", None, [_vp])
 _sig("cpt_tracer_set_max_depth", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_channel", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_integrator", C.c_int, [_vp, C.c_int])
+_sig("cpt_tracer_set_wavefront_tail", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
 _sig("cpt_tracer_update", C.c_int, [_vp])
@@ -266,6 +267,9 @@ class Tracer:
 
     def set_integrator(self, mode):
         check(lib.cpt_tracer_set_integrator(self.h, mode))
+
+    def set_wavefront_tail(self, bounces):
+        check(lib.cpt_tracer_set_wavefront_tail(self.h, bounces))
 
     def set_channel(self, c):
         check(lib.cpt_tracer_set_channel(self.h, c))

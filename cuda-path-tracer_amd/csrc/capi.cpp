@@ -310,6 +310,7 @@ int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
     t->tracer->SetIntegrator(mode);
     return CPT_OK;
 }
+int cpt_tracer_set_wavefront_tail(cpt_tracer *t, int bounces) { TRACER_OR_FAIL(t); t->tracer->SetWavefrontTail(bounces); return CPT_OK; }
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on) { TRACER_OR_FAIL(t); t->tracer->SetProfileBuild(on != 0); return CPT_OK; }
 int cpt_tracer_build_buffers(cpt_tracer *t) {
     TRACER_OR_FAIL(t);

@@ -223,7 +223,7 @@ void PathTracer::BuildInstancesAndLights() {
     if (!instances.empty()) instance_table_.Allocate(sizeof(cpt::InstanceDev) * instances.size(), instances.data(), stream_);
     if (!materials.empty()) material_table_.Allocate(sizeof(cpt::BsdfDev) * materials.size(), materials.data(), stream_);
     if (!lights.empty()) light_table_.Allocate(sizeof(uint32_t) * lights.size(), lights.data(), stream_);
-    counters_.Allocate(sizeof(cpt::Counters));
+    counters_.Allocate(sizeof(cpt::Counters) * cpt::kCounterSlots);
     counters_.Zero(stream_);
 
     scene_dev_.instances = instance_table_.TypedGpuData<cpt::InstanceDev>();
@@ -260,32 +260,47 @@ void PathTracer::Update() {
 void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     size_t slots = cpt::wavefront_slots(p.width, p.height);
     if (wf_.capacity != slots) {
+        size_t segments = slots / cpt::kSegmentSlots;
         wf_state_.Allocate(slots * 8 * sizeof(float4));
-        wf_queues_.Allocate((slots * 3 + 8) * sizeof(uint32_t));
+        wf_queues_.Allocate((slots * 2 + segments * 2 + cpt::kControlWords) * sizeof(uint32_t));
         float4 *s = wf_state_.TypedGpuData<float4>();
         wf_.ray_o = s; wf_.ray_d = s + slots; wf_.thr = s + 2 * slots; wf_.col = s + 3 * slots;
         wf_.hit = s + 4 * slots; wf_.sh_o = s + 5 * slots; wf_.sh_d = s + 6 * slots; wf_.pending = s + 7 * slots;
         uint32_t *q = wf_queues_.TypedGpuData<uint32_t>();
-        wf_.counts = q;
-        wf_.queue[0] = q + 8; wf_.queue[1] = q + 8 + slots; wf_.shadow_queue = q + 8 + 2 * slots;
+        wf_.control = q;
+        wf_.queue = q + cpt::kControlWords;
+        wf_.shadow_queue = wf_.queue + slots;
+        wf_.seg_count = wf_.shadow_queue + slots;
+        wf_.shadow_count = wf_.seg_count + segments;
         wf_.capacity = (uint32_t)slots;
+        wf_.segments = (uint32_t)segments;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
         wf_resident_blocks_ = cpt::wavefront_resident_blocks(device);
     }
+    const uint32_t resident = (uint32_t)wf_resident_blocks_;
     rc_check(cpt::wavefront_begin_sample(scene_dev_, p, wf_, stream_), "wavefront generate");
-    if (p.max_depth != 0xffffffffu && p.max_depth <= 64) {
-        for (uint32_t b = 0; b <= p.max_depth; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b & 1u, (uint32_t)wf_resident_blocks_, stream_), "wavefront bounce");
+    // a path asks for at most max_depth + 1 closest-hit rays (camera ray included)
+    const bool bounded = p.max_depth != 0xffffffffu;
+    const uint32_t needed = bounded ? p.max_depth + 1 : 0xffffffffu;
+    const bool pure = wavefront_tail_ < 0;
+    uint32_t queued = needed;
+    if (!pure && (uint32_t)wavefront_tail_ < queued) queued = (uint32_t)wavefront_tail_;
+    if (queued != 0xffffffffu) {
+        for (uint32_t b = 0; b < queued; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b + 1, resident, stream_), "wavefront bounce");
+        if (queued < needed) rc_check(cpt::wavefront_finish(scene_dev_, p, wf_, resident, stream_), "wavefront finish");
         return;
     }
-    // unbounded depth: Russian roulette ends every path; look at the live count every few bounces
-    uint32_t bounce = 0;
+    // queues only, unbounded depth: Russian roulette ends every path; the shade kernel stores the
+    // bounce number while any path goes on, read it back after each group of bounces
+    uint32_t bounce = 0, group = 4;
     for (;;) {
-        for (int k = 0; k < 4; k++, bounce++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, bounce & 1u, (uint32_t)wf_resident_blocks_, stream_), "wavefront bounce");
-        uint32_t live = 0;
-        CPT_HIP(hipMemcpyAsync(&live, wf_.counts + (bounce & 1u), sizeof(live), hipMemcpyDeviceToHost, stream_));
+        for (uint32_t k = 0; k < group; k++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, ++bounce, resident, stream_), "wavefront bounce");
+        uint32_t marker = 0;
+        CPT_HIP(hipMemcpyAsync(&marker, wf_.control + cpt::kControlLiveMarker, sizeof(marker), hipMemcpyDeviceToHost, stream_));
         CPT_HIP(hipStreamSynchronize(stream_));
-        if (live == 0 || bounce > p.max_depth || bounce >= (1u << 16)) break;
+        if (marker != bounce || bounce >= (1u << 20)) break;
+        if (group < 64) group *= 2;
     }
 }
 
@@ -299,7 +314,7 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         return;
     }
     if (!queue_.Size()) {
-        queue_.Allocate(2 * sizeof(uint32_t));
+        queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
@@ -357,12 +372,14 @@ float PathTracer::UpdateTimed(uint32_t count) {
 }
 
 void PathTracer::ReadCounters(unsigned long long out[5]) {
-    cpt::Counters c{};
-    if (counters_.Size()) {
-        CPT_HIP(hipMemcpyAsync(&c, counters_.GpuData(), sizeof(c), hipMemcpyDeviceToHost, stream_));
-        CPT_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < 5; i++) out[i] = 0;
+    if (!counters_.Size()) return;
+    std::vector<cpt::Counters> slots(cpt::kCounterSlots);
+    CPT_HIP(hipMemcpyAsync(slots.data(), counters_.GpuData(), sizeof(cpt::Counters) * cpt::kCounterSlots, hipMemcpyDeviceToHost, stream_));
+    CPT_HIP(hipStreamSynchronize(stream_));
+    for (const cpt::Counters &c : slots) {
+        out[0] += c.rays; out[1] += c.node_visits; out[2] += c.tri_tests; out[3] += c.paths; out[4] += c.shades;
     }
-    out[0] = c.rays; out[1] = c.node_visits; out[2] = c.tri_tests; out[3] = c.paths; out[4] = c.shades;
 }
 
 void PathTracer::ResetCounters() {

@@ -33,6 +33,8 @@ public:
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
     // 2: wavefront (ray queues in HBM, one kernel sequence per bounce)
     void SetIntegrator(int mode) { integrator_ = mode; }
+    // wavefront only: queue bounces before the persistent finishing launch; negative = queues only
+    void SetWavefrontTail(int bounces) { wavefront_tail_ = bounces; }
     void Synchronize();
     uint32_t CurrentSpp() const { return curr_spp_; }
     uint32_t NumLights() const { return num_lights_; }
@@ -90,6 +92,7 @@ private:
     cpt::HipBuffer wf_state_, wf_queues_;
     cpt::WavefrontBuffers wf_{};
     int wf_resident_blocks_ = 0;
+    int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 
     cpt::BuildWorkspace workspace_;

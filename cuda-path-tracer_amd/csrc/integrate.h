@@ -68,22 +68,40 @@ __device__ inline void film_accumulate(const RenderParams &p, uint32_t pixel_ind
     *out = res;
 }
 
+// sum over the 64 lanes of a wave, result in every lane
+__device__ inline unsigned long long wave_sum(uint32_t v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)s, off, 64), hi = __shfl_xor((uint32_t)(s >> 32), off, 64);
+        s += ((unsigned long long)hi << 32) | lo;
+    }
+    return s;
+}
+
+// end of a kernel: per-wave sums -> per-workgroup sums in LDS -> five atomics into the workgroup's
+// counter slot.  Every thread of the workgroup must call it.
 __device__ inline void flush_counters(const SceneDev &sc, const LaneCounters &cnt, uint32_t paths, unsigned long long *block_cnt) {
     if (!sc.counters) return;
     if (threadIdx.x < 5) block_cnt[threadIdx.x] = 0;
     __syncthreads();
-    atomicAdd(&block_cnt[0], (unsigned long long)cnt.rays);
-    atomicAdd(&block_cnt[1], (unsigned long long)cnt.nodes);
-    atomicAdd(&block_cnt[2], (unsigned long long)cnt.tris);
-    atomicAdd(&block_cnt[3], (unsigned long long)paths);
-    atomicAdd(&block_cnt[4], (unsigned long long)cnt.shades);
+    const unsigned long long w0 = wave_sum(cnt.rays), w1 = wave_sum(cnt.nodes), w2 = wave_sum(cnt.tris), w3 = wave_sum(paths),
+                             w4 = wave_sum(cnt.shades);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&block_cnt[0], w0);
+        atomicAdd(&block_cnt[1], w1);
+        atomicAdd(&block_cnt[2], w2);
+        atomicAdd(&block_cnt[3], w3);
+        atomicAdd(&block_cnt[4], w4);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sc.counters->rays, block_cnt[0]);
-        atomicAdd(&sc.counters->node_visits, block_cnt[1]);
-        atomicAdd(&sc.counters->tri_tests, block_cnt[2]);
-        atomicAdd(&sc.counters->paths, block_cnt[3]);
-        atomicAdd(&sc.counters->shades, block_cnt[4]);
+        Counters *slot = sc.counters + (blockIdx.x & (kCounterSlots - 1));
+        if (block_cnt[0]) atomicAdd(&slot->rays, block_cnt[0]);
+        if (block_cnt[1]) atomicAdd(&slot->node_visits, block_cnt[1]);
+        if (block_cnt[2]) atomicAdd(&slot->tri_tests, block_cnt[2]);
+        if (block_cnt[3]) atomicAdd(&slot->paths, block_cnt[3]);
+        if (block_cnt[4]) atomicAdd(&slot->shades, block_cnt[4]);
     }
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "segment_fetch.h"
 
 namespace cpt {
 
@@ -11,9 +12,10 @@ namespace cpt {
 int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream);
 
 // The same sample through the persistent, lane-regenerating kernel.  `queue` is a device array of
-// two uint32 counters owned by the caller: queue[parity] must be zero when the launch starts (the
-// kernel zeroes queue[parity ^ 1] for the next launch, so alternate parity 0,1,0,.. on one stream
-// after zeroing both once).  max_blocks: render_regen_resident_blocks() of the device.
+// kRegenQueueWords uint32 owned by the caller: two sets of tile cursors.  Set `parity` must be zero
+// when the launch starts (the kernel zeroes the other set for the next launch, so alternate parity
+// 0,1,0,.. on one stream after zeroing everything once).  max_blocks: render_regen_resident_blocks() of the device.
+constexpr uint32_t kRegenQueueWords = 2 * kCursorSetWords;
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream);
 int render_regen_resident_blocks(int device);
 

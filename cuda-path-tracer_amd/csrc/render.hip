@@ -5,7 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
-#include "integrate.h"
+#include "path_lane.h"
+#include "segment_fetch.h"
 
 namespace cpt {
 
@@ -105,15 +106,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
     flush_counters(sc, cnt, active ? 1u : 0u, s_cnt);
 }
 
-constexpr uint32_t kBatchSlots = 256;     // pixel slots (four 8x8 tiles) a wave takes from the queue at a time
-
 // Persistent variant of the same integrator: every lane still follows exactly one path at a
 // time with the reference's operation order, but a lane whose path ends picks up the next pixel
-// at once instead of idling until the slowest path of its wave is done.  Pixel slots (8x8 tiles,
-// 64 consecutive slots each) are handed out in batches through one device-wide counter; idle
-// lanes are found with a ballot and numbered with a popcount prefix.  One trip of the loop is:
-// closest-hit trace for every live lane (camera rays and bounce rays mixed), shading + light
-// sampling, any-hit trace for the lanes with a shadow ray, BSDF sampling.
+// at once instead of idling until the slowest path of its wave is done.  Pixel slots are handed
+// out one 8x8 tile at a time (SegmentFetch: a cursor per XCD over a contiguous band of tiles, so
+// neighbouring tiles share an L2); idle lanes are found with a ballot and numbered with a popcount
+// prefix.  One trip of the loop is path_trip().
 __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -124,134 +122,36 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
-    const uint32_t total_slots = tiles_x * tiles_y * 64;
-    if (blockIdx.x == 0 && threadIdx.x == 0) queue[parity ^ 1u] = 0;     // the next launch's counter
+    uint32_t *cursors = queue + parity * kCursorSetWords;
+    zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
 
-    uint32_t next = 0, end = 0;
-    bool exhausted = false;
-    // per-lane path state
-    bool alive = false, primary = false, last_specular = false;
-    uint32_t pixel_index = 0, depth = 0;
-    float last_pdf = 0.0f;
-    Sampler sampler{0};
-    V3 ro = v3(0.0f), rd = v3(0.0f), throughput = v3(0.0f), color = v3(0.0f);
+    SegmentFetch f;
+    PathLane l;
 
     for (;;) {
         // ---- hand new pixels to idle lanes
-        unsigned long long idle = __ballot(!alive);
-        while (idle != 0ull && !exhausted) {
-            if (next >= end) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(&queue[parity], kBatchSlots);
-                b = __shfl(b, 0, 64);
-                if (b >= total_slots) { exhausted = true; break; }
-                next = b;
-                end = min(b + kBatchSlots, total_slots);
-            }
+        unsigned long long idle = __ballot(!l.alive);
+        while (idle != 0ull && !f.exhausted) {
+            if (f.next >= f.end && !f.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
-            const uint32_t take = min((uint32_t)__popcll(idle), end - next);
-            if (!alive && rank < take) {
-                const uint32_t slot = next + rank;
+            const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
+            if (!l.alive && rank < take) {
+                const uint32_t slot = f.next + rank;
                 const uint32_t tile = slot >> 6, k = slot & 63u;
                 const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
                 if (px < p.width && py < p.height) {
-                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
-                    alive = true; primary = true; last_specular = false;
-                    depth = 0; color = v3(0.0f); throughput = v3(1.0f);
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
+                    l.alive = true; l.primary = true; l.last_specular = false;
+                    l.depth = 0; l.color = v3(0.0f); l.throughput = v3(1.0f);
                     paths++;
                 }
             }
-            next += take;
-            idle = __ballot(!alive);
+            f.next += take;
+            idle = __ballot(!l.alive);
         }
-        if (__ballot(alive) == 0ull) break;        // nothing in flight and the queue is empty
+        if (__ballot(l.alive) == 0ull) break;        // nothing in flight and every tile is handed out
 
-        // ---- extend
-        Hit hit;
-        float tmax = kRayTMax;
-        const bool got = trace<false>(sc, alive, ro, rd, kRayTMin, tmax, hit, st, cnt);
-
-        // ---- shade, pick a light sample (src/kernels/integrator/path.cu:9-48, :57-80)
-        bool finish = false, need_shadow = false;
-        V3 pos = v3(0.0f), normal = v3(0.0f, 0.0f, 1.0f), ldir = v3(0.0f), lweight = v3(0.0f);
-        float lpdf = 0.0f, ldist = 0.0f;
-        uint32_t material = 0;
-        if (alive) {
-            if (!got) {
-                finish = true;
-            } else {
-                Surface surface = shading_surface(sc, hit, cnt);
-                if (primary) {
-                    primary = false;
-                    if (p.channel == 1) { color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
-                    else { color = surface.bsdf.emission; if (!is_zero(color)) finish = true; }
-                } else if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
-                    float mis_weight = 1.0f;
-                    if (!last_specular) {
-                        float light_pdf = surface.vertex.pdf * path_to_solid_angle_jacobian(ro, surface.vertex.position, surface.vertex.normal) *
-                                          sc.light_pick_pdf;
-                        mis_weight = power_heuristic(last_pdf, light_pdf);
-                    }
-                    color = color + throughput * mis_weight * surface.bsdf.emission;
-                    finish = true;
-                } else {
-                    float rr_prop = gmin(gmax(luminance(throughput), 0.01f), 0.95f);
-                    if (sampler.next1d() > rr_prop) finish = true;
-                    else { throughput = throughput / rr_prop; depth++; }
-                }
-                if (!finish && !(depth < p.max_depth)) finish = true;
-                if (!finish) {
-                    pos = surface.vertex.position;
-                    normal = surface.vertex.normal;
-                    material = sc.instances[hit.inst].material;
-                    if (!bsdf_is_delta(surface.bsdf)) {
-                        float r1 = sampler.next1d();
-                        uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
-                        V2 r2 = sampler.next2d();
-                        LightSample ls = light_sample(sc, sc.lights[index], pos, r2);
-                        ls.pdf *= sc.light_pick_pdf;
-                        ls.weight = ls.weight / sc.light_pick_pdf;
-                        if (ls.pdf > 0.0f) { need_shadow = true; ldir = ls.dir; lweight = ls.weight; lpdf = ls.pdf; ldist = ls.dist; }
-                    }
-                }
-            }
-        }
-
-        // ---- shadow rays
-        Hit dummy;
-        float smax = ldist - kShadowRayEps;
-        const bool occluded = trace<true>(sc, need_shadow, pos, ldir, kRayTMin, smax, dummy, st, cnt);
-
-        // ---- light contribution and next direction (path.cu:38-55)
-        if (alive && !finish) {
-            const BsdfDev bsdf = sc.materials[material];
-            Frame frame = Frame::from_normal(normal);
-            V3 wo = frame.to_local(-rd);
-            if (need_shadow && !occluded) {
-                V3 wi = frame.to_local(ldir);
-                float bp = bsdf_pdf(bsdf, wo, wi);
-                float mis_weight = power_heuristic(lpdf, bp);
-                color = color + throughput * mis_weight * lweight * bsdf_eval(bsdf, wo, wi);
-            }
-            float b1 = sampler.next1d();
-            V2 b2 = sampler.next2d();
-            BsdfSample bs = bsdf_sample(bsdf, wo, b1, b2);
-            if (bs.pdf == 0.0f) {
-                finish = true;
-            } else {
-                throughput = throughput * bs.weight;
-                ro = pos;
-                rd = frame.to_world(bs.wi);
-                last_pdf = bs.pdf;
-                last_specular = bs.lobe == kLobeSpecular;
-            }
-        }
-
-        // ---- film (path.cu:99-104)
-        if (alive && finish) {
-            film_accumulate(p, pixel_index, color);
-            alive = false;
-        }
+        path_trip(sc, p, l, st, cnt);
     }
     flush_counters(sc, cnt, paths, s_cnt);
 }
@@ -362,9 +262,9 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
 }
 
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream) {
-    uint32_t slots = ((p.width + 7) / 8) * ((p.height + 7) / 8) * 64;
-    if (slots == 0) return 0;
-    uint32_t want = (slots + kBatchSlots * (kTraceBlock / 64) - 1) / (kBatchSlots * (kTraceBlock / 64));
+    uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
+    if (tiles == 0) return 0;
+    uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? want : max_blocks;
     hipLaunchKernelGGL(k_render_regen, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
     return (int)hipGetLastError();

@@ -13,7 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
-#include "integrate.h"
+#include "path_lane.h"
+#include "segment_fetch.h"
 
 namespace cpt {
 
@@ -22,23 +23,20 @@ namespace {
 constexpr uint32_t kPrimaryBit = 0x80000000u;
 constexpr uint32_t kSpecularBit = 0x40000000u;
 constexpr uint32_t kPixelMask = 0x3fffffffu;
-constexpr uint32_t kFetchBatch = 256;      // queue entries a wave reserves at a time
 constexpr int kRefillIdleLanes = 16;       // refill as soon as this many lanes of a wave are idle
 
-// appends one entry per lane with flag set; one atomic per wave
-__device__ inline void queue_append(uint32_t *queue, uint32_t *count, bool flag, uint32_t value) {
+// packs the flagged lanes' values at the start of the wave's segment; one wave = one segment
+__device__ inline uint32_t segment_publish(uint32_t *queue, uint32_t *counts, uint32_t seg, bool flag, uint32_t value) {
     const unsigned long long m = __ballot(flag);
-    if (m == 0ull) return;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, (int)leader, 64);
-    if (flag) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    if (flag) queue[seg * kSegmentSlots + __popcll(m & ((1ull << lane) - 1ull))] = value;
+    if (lane == 0) counts[seg] = (uint32_t)__popcll(m);
+    return (uint32_t)__popcll(m);
 }
 
 // one lane per pixel slot (8x8 tiles): camera ray + fresh path state, src/kernels/integrator/path.cu:86-96
 __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+    __shared__ unsigned long long s_cnt[5];
     const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
     const uint32_t tiles_x = (p.width + 7) / 8;
     const uint32_t tile = slot >> 6, k = slot & 63u;
@@ -54,19 +52,16 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
         wb.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
         wb.col[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    queue_append(wb.queue[0], &wb.counts[0], valid, slot);
-    if (sc.counters && valid) {
-        const unsigned long long m = __ballot(true);
-        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&sc.counters->paths, (unsigned long long)__popcll(m));
-    }
+    if (tile < wb.segments) segment_publish(wb.queue, wb.seg_count, tile, valid, slot);
+    flush_counters(sc, LaneCounters{}, valid ? 1u : 0u, s_cnt);
 }
 
-// Persistent traversal over a queue of path ids.  ANY = false: closest hit of the path's current
+// Persistent traversal over the queued paths.  ANY = false: closest hit of the path's current
 // ray, result to wb.hit.  ANY = true: the path's shadow ray; an unoccluded ray adds the pending
 // light contribution to the path's colour, and a path that was only waiting for this ray is
 // written to the film.
 template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t parity) {
+__global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     TraceStack st;
@@ -74,31 +69,25 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, Render
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t *queue = ANY ? wb.shadow_queue : wb.queue[parity];
-    const uint32_t total = ANY ? wb.counts[2] : wb.counts[parity];
-    uint32_t *cursor = &wb.counts[ANY ? 4 : 3];
+    const uint32_t *queue = ANY ? wb.shadow_queue : wb.queue;
+    const uint32_t *counts = ANY ? wb.shadow_count : wb.seg_count;
+    uint32_t *cursors = wb.control + (ANY ? kControlShadowCursors : kControlExtendCursors);
+    // the shadow pass of the previous bounce is over, the one of this bounce has not begun
+    if (!ANY) zero_cursors(wb.control + kControlShadowCursors);
 
-    uint32_t next = 0, end = 0;
-    bool exhausted = total == 0;
+    SegmentFetch f;
     Traversal t;
     bool have = false;
     uint32_t path = 0;
     for (;;) {
         unsigned long long idle = __ballot(!have);
-        if (!exhausted && (__popcll(idle) >= kRefillIdleLanes || idle == ~0ull)) {
-            while (idle != 0ull && !exhausted) {
-                if (next >= end) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(cursor, kFetchBatch);
-                    b = __shfl(b, 0, 64);
-                    if (b >= total) { exhausted = true; break; }
-                    next = b;
-                    end = min(b + kFetchBatch, total);
-                }
+        if (!f.exhausted && (__popcll(idle) >= kRefillIdleLanes || idle == ~0ull)) {
+            while (idle != 0ull) {
+                if (f.next >= f.end && !f.advance(counts, cursors, wb.segments, blockIdx.x, lane)) break;
                 const uint32_t rank = __popcll(idle & lt_mask);
-                const uint32_t take = min((uint32_t)__popcll(idle), end - next);
+                const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
                 if (!have && rank < take) {
-                    path = queue[next + rank];
+                    path = queue[f.next + rank];
                     if (ANY) {
                         float4 o = wb.sh_o[path], d = wb.sh_d[path];
                         t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, o.w, cnt);
@@ -108,7 +97,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, Render
                     }
                     have = true;
                 }
-                next += take;
+                f.next += take;
                 idle = __ballot(!have);
             }
         }
@@ -136,21 +125,17 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, Render
 // Everything the integrator does between two rays of one path (path.cu:12-80 in the order the
 // statements run for one path): primary-hit special cases, emitter hit with MIS, Russian roulette,
 // depth test, light sample (shadow ray + pending contribution), BSDF sample (next ray).
-__global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t parity) {
+__global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t bounce_id) {
     __shared__ unsigned long long s_cnt[5];
     LaneCounters cnt;
-    const uint32_t total = wb.counts[parity];
-    const uint32_t *queue = wb.queue[parity];
-    uint32_t *next_queue = wb.queue[parity ^ 1u];
-    uint32_t *next_count = &wb.counts[parity ^ 1u];
-    const uint32_t rounds = (total + gridDim.x * 256 - 1) / (gridDim.x * 256);
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        const bool valid = i < total;
+    zero_cursors(wb.control + kControlExtendCursors);       // the extend pass of this bounce is over
+    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg < wb.segments) {
+        const bool valid = lane < wb.seg_count[seg];
         bool cont = false, need_shadow = false;
         uint32_t path = 0;
         if (valid) {
-            path = queue[i];
+            path = wb.queue[seg * kSegmentSlots + lane];
             float4 fo = wb.ray_o[path], fd = wb.ray_d[path], ft = wb.thr[path], fc = wb.col[path], fh = wb.hit[path];
             uint32_t tag = __float_as_uint(fo.w);
             const uint32_t pixel_index = tag & kPixelMask;
@@ -241,52 +226,97 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
             }
             if (finish && !need_shadow) film_accumulate(p, pixel_index, color);
         }
-        queue_append(next_queue, next_count, cont, path);
-        queue_append(wb.shadow_queue, &wb.counts[2], need_shadow, path);
+        // every lane has read its entry of the old list by now (one wave, program order)
+        const uint32_t live = segment_publish(wb.queue, wb.seg_count, seg, cont, path);
+        segment_publish(wb.shadow_queue, wb.shadow_count, seg, need_shadow, path);
+        if (live != 0 && lane == 0) wb.control[kControlLiveMarker] = bounce_id;    // same value from every wave
     }
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
-// end of one bounce: the queue just consumed and the shadow queue become empty, cursors rewind
-__global__ void k_wf_reset(WavefrontBuffers wb, uint32_t parity) {
-    if (threadIdx.x == 0) {
-        wb.counts[parity] = 0;
-        wb.counts[2] = 0;
-        wb.counts[3] = 0;
-        wb.counts[4] = 0;
+// Finishes what the queue still holds: lanes load a queued path's state and run it to its end
+// in registers, picking up another queued path whenever one ends.
+__global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    TraceStack st;
+    st.lds = s_stack;
+    LaneCounters cnt;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t *cursors = wb.control + kControlFinishCursors;
+    SegmentFetch f;
+    PathLane l;
+    for (;;) {
+        unsigned long long idle = __ballot(!l.alive);
+        while (idle != 0ull && !f.exhausted) {
+            if (f.next >= f.end && !f.advance(wb.seg_count, cursors, wb.segments, blockIdx.x, lane)) break;
+            const uint32_t rank = __popcll(idle & lt_mask);
+            const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
+            if (!l.alive && rank < take) {
+                const uint32_t path = wb.queue[f.next + rank];
+                const float4 fo = wb.ray_o[path], fd = wb.ray_d[path], ft = wb.thr[path], fc = wb.col[path];
+                const uint32_t tag = __float_as_uint(fo.w);
+                l.alive = true;
+                l.primary = (tag & kPrimaryBit) != 0;
+                l.last_specular = (tag & kSpecularBit) != 0;
+                l.pixel_index = tag & kPixelMask;
+                l.depth = __float_as_uint(ft.w);
+                l.last_pdf = fc.w;
+                l.sampler.state = __float_as_uint(fd.w);
+                l.ro = v3(fo.x, fo.y, fo.z); l.rd = v3(fd.x, fd.y, fd.z);
+                l.throughput = v3(ft.x, ft.y, ft.z); l.color = v3(fc.x, fc.y, fc.z);
+            }
+            f.next += take;
+            idle = __ballot(!l.alive);
+        }
+        if (__ballot(l.alive) == 0ull) break;
+        path_trip(sc, p, l, st, cnt);
     }
+    flush_counters(sc, cnt, 0u, s_cnt);
 }
 
 }  // namespace
 
-size_t wavefront_slots(uint32_t width, uint32_t height) { return (size_t)((width + 7) / 8) * ((height + 7) / 8) * 64; }
+size_t wavefront_slots(uint32_t width, uint32_t height) { return (size_t)((width + 7) / 8) * ((height + 7) / 8) * kSegmentSlots; }
 
 int wavefront_resident_blocks(int device) {
-    int a = 0, b = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_wf_trace<false>, kTraceBlock, 0) != hipSuccess || a < 1) a = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_wf_trace<true>, kTraceBlock, 0) != hipSuccess || b < 1) b = 1;
+    int best = 1 << 30, cus = 0;
+    const void *kernels[3] = {(const void *)k_wf_trace<false>, (const void *)k_wf_trace<true>, (const void *)k_wf_finish};
+    for (const void *k : kernels) {
+        int a = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k, kTraceBlock, 0) != hipSuccess || a < 1) a = 1;
+        if (a < best) best = a;
+    }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-    return (a < b ? a : b) * cus;
+    return best * cus;
+}
+
+static uint32_t persistent_blocks(const WavefrontBuffers &wb, uint32_t resident_blocks) {
+    uint32_t want = (wb.segments + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
+    uint32_t blocks = want < resident_blocks ? want : resident_blocks;
+    return blocks ? blocks : 1;
 }
 
 int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(wb.counts, 0, 8 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(wb.control, 0, kControlWords * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     uint32_t blocks = (wb.capacity + 255) / 256;
     hipLaunchKernelGGL(k_wf_generate, dim3(blocks), dim3(256), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 
-int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t parity, uint32_t resident_blocks, hipStream_t stream) {
-    uint32_t want = (wb.capacity + kFetchBatch * (kTraceBlock / 64) - 1) / (kFetchBatch * (kTraceBlock / 64));
-    uint32_t blocks = want < resident_blocks ? want : resident_blocks;
-    if (blocks == 0) blocks = 1;
-    uint32_t shade_blocks = (wb.capacity + 255) / 256;
-    if (shade_blocks > 4 * resident_blocks) shade_blocks = 4 * resident_blocks;
-    hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb, parity);
-    hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, parity);
-    hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb, parity);
-    hipLaunchKernelGGL(k_wf_reset, dim3(1), dim3(64), 0, stream, wb, parity);
+int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t bounce_id, uint32_t resident_blocks, hipStream_t stream) {
+    const uint32_t blocks = persistent_blocks(wb, resident_blocks);
+    const uint32_t shade_blocks = (wb.segments + 3) / 4;
+    hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
+    hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    return (int)hipGetLastError();
+}
+
+int wavefront_finish(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t resident_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wf_finish, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 

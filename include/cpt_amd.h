@@ -106,6 +106,11 @@ int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour,
  * ray queues in device memory, extend / shade / shadow kernels per bounce, traversal kernels that
  * refill idle lanes from the queue.  Same image in all three. */
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
+/* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
+ * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette
+ * paths costs a kernel sequence per bounce otherwise).  Negative = never, queues to the end
+ * (with unbounded depth the host then reads a live marker back every few bounces).  Default 3. */
+int cpt_tracer_set_wavefront_tail(cpt_tracer *t, int bounces);
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
 int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */
 int cpt_tracer_update(cpt_tracer *t);                               /* PathTracer::Update: one more sample per pixel (asynchronous) */

@@ -1,5 +1,5 @@
 """Small driver for rocprofv3 passes: N launches of the bounce-loop kernel on cornell-box-glass
-(no torch, no oracle).  usage: python scripts/prof_render.py [steps] [width] [depth] [integrator]"""
+(no torch, no oracle).  usage: python scripts/prof_render.py [steps] [width] [depth] [integrator] [wavefront tail]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,6 +13,8 @@ d = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box-glass")
 scene = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
 tr = cpt.Tracer(scene, width, width, max_depth=depth)
 tr.set_integrator(mode)
+if len(sys.argv) > 5:
+    tr.set_wavefront_tail(int(sys.argv[5]))
 tr.build_buffers()
 tr.update(2); tr.synchronize(); tr.reset_counters()
 ms = tr.update_timed(steps)

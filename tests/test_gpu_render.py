@@ -143,17 +143,19 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
     must be identical, not merely close; so must their ray counts."""
     objs, cam = cornell(glass=True)
     imgs, rays = [], []
-    for mode in (0, 1, 2):
+    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1)):
         sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=depth)     # not a multiple of the 8x8 tiles
         tr.set_integrator(mode)
+        if tail is not None:
+            tr.set_wavefront_tail(tail)     # queues only / persistent finish right away / after one bounce
         tr.update(6)
         imgs.append(tr.film())
         c = tr.counters()
         assert c["paths"] == 200 * 120 * 6
         rays.append((c["rays"], c["node_visits"], c["tri_tests"], c["shades"]))
-    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
-    assert np.array_equal(imgs[0].view(np.uint32), imgs[2].view(np.uint32))
-    assert rays[0] == rays[1] == rays[2]
+    for k in range(1, len(imgs)):
+        assert np.array_equal(imgs[0].view(np.uint32), imgs[k].view(np.uint32)), k
+        assert rays[0] == rays[k], k
 
 
 def test_wavefront_sum_mode_and_normal_channel(cpt):
