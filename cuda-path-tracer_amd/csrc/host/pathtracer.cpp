@@ -262,7 +262,7 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     if (wf_.capacity != slots) {
         size_t segments = slots / cpt::kSegmentSlots;
         wf_state_.Allocate(slots * 8 * sizeof(float4));
-        wf_queues_.Allocate((slots * 2 + segments * 2 + cpt::kControlWords) * sizeof(uint32_t));
+        wf_queues_.Allocate((slots * 2 + cpt::kControlWords) * sizeof(uint32_t));
         float4 *s = wf_state_.TypedGpuData<float4>();
         wf_.ray_o = s; wf_.ray_d = s + slots; wf_.thr = s + 2 * slots; wf_.col = s + 3 * slots;
         wf_.hit = s + 4 * slots; wf_.sh_o = s + 5 * slots; wf_.sh_d = s + 6 * slots; wf_.pending = s + 7 * slots;
@@ -270,13 +270,12 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
         wf_.control = q;
         wf_.queue = q + cpt::kControlWords;
         wf_.shadow_queue = wf_.queue + slots;
-        wf_.seg_count = wf_.shadow_queue + slots;
-        wf_.shadow_count = wf_.seg_count + segments;
         wf_.capacity = (uint32_t)slots;
         wf_.segments = (uint32_t)segments;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
         wf_resident_blocks_ = cpt::wavefront_resident_blocks(device);
+        wf_finish_blocks_ = cpt::wavefront_finish_resident_blocks(device);
     }
     const uint32_t resident = (uint32_t)wf_resident_blocks_;
     rc_check(cpt::wavefront_begin_sample(scene_dev_, p, wf_, stream_), "wavefront generate");
@@ -288,7 +287,7 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     if (!pure && (uint32_t)wavefront_tail_ < queued) queued = (uint32_t)wavefront_tail_;
     if (queued != 0xffffffffu) {
         for (uint32_t b = 0; b < queued; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b + 1, resident, stream_), "wavefront bounce");
-        if (queued < needed) rc_check(cpt::wavefront_finish(scene_dev_, p, wf_, resident, stream_), "wavefront finish");
+        if (queued < needed) rc_check(cpt::wavefront_finish(scene_dev_, p, wf_, (uint32_t)wf_finish_blocks_, stream_), "wavefront finish");
         return;
     }
     // queues only, unbounded depth: Russian roulette ends every path; the shade kernel stores the

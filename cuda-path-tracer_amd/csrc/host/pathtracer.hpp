@@ -91,7 +91,7 @@ private:
     void LaunchWavefront(const cpt::RenderParams &p);
     cpt::HipBuffer wf_state_, wf_queues_;
     cpt::WavefrontBuffers wf_{};
-    int wf_resident_blocks_ = 0;
+    int wf_resident_blocks_ = 0, wf_finish_blocks_ = 0;
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 

@@ -125,18 +125,18 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
     uint32_t *cursors = queue + parity * kCursorSetWords;
     zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
 
-    SegmentFetch f;
+    SegmentFetchT<false> f;
     PathLane l;
 
     for (;;) {
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!l.alive);
         while (idle != 0ull && !f.exhausted) {
-            if (f.next >= f.end && !f.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            if (f.remaining() == 0 && !f.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
-            const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
+            const uint32_t take = min((uint32_t)__popcll(idle), f.remaining());
+            const uint32_t slot = f.entry(rank);
             if (!l.alive && rank < take) {
-                const uint32_t slot = f.next + rank;
                 const uint32_t tile = slot >> 6, k = slot & 63u;
                 const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
                 if (px < p.width && py < p.height) {
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
                     paths++;
                 }
             }
-            f.next += take;
+            f.consumed += take;
             idle = __ballot(!l.alive);
         }
         if (__ballot(l.alive) == 0ull) break;        // nothing in flight and every tile is handed out

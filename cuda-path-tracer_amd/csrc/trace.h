@@ -26,20 +26,25 @@ struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; };
 
 // Per-lane stack of (node reference, entry distance) pairs.  Entry e of lane l lives at
 // lds[e * 256 + l]: lanes of a wave always touch consecutive 8-byte slots, whatever their depths.
-struct TraceStack {
-    uint2 *lds;
+// LDS_ENTRIES is a kernel's trade between LDS per workgroup (occupancy) and how deep a tree goes
+// before entries land in private memory.
+template <int LDS_ENTRIES>
+struct TraceStackT {
+    static constexpr int kLdsEntries = LDS_ENTRIES;
+    uint2 *lds;         // LDS_ENTRIES * kTraceBlock entries
     uint2 spill[kSpillEntries];
     __device__ inline void push(uint32_t sp, uint32_t node, float t0) {
         uint2 e = make_uint2(node, __float_as_uint(t0));
-        if (sp < kLdsStackEntries) lds[sp * kTraceBlock + threadIdx.x] = e;
-        else if (sp < kLdsStackEntries + kSpillEntries) spill[sp - kLdsStackEntries] = e;
+        if (sp < LDS_ENTRIES) lds[sp * kTraceBlock + threadIdx.x] = e;
+        else if (sp < LDS_ENTRIES + kSpillEntries) spill[sp - LDS_ENTRIES] = e;
     }
     __device__ inline uint2 at(uint32_t sp) const {
-        if (sp < kLdsStackEntries) return lds[sp * kTraceBlock + threadIdx.x];
-        if (sp < kLdsStackEntries + kSpillEntries) return spill[sp - kLdsStackEntries];
+        if (sp < LDS_ENTRIES) return lds[sp * kTraceBlock + threadIdx.x];
+        if (sp < LDS_ENTRIES + kSpillEntries) return spill[sp - LDS_ENTRIES];
         return make_uint2(0u, 0x7fc00000u);   // NaN entry distance: never entered
     }
 };
+using TraceStack = TraceStackT<kLdsStackEntries>;
 
 struct Hit { uint32_t inst, prim; float u, v; };
 
@@ -169,8 +174,8 @@ struct Traversal {
     __device__ inline bool live() const { return cur != kNoNode; }
 
     // returns false when no lane of the wave that called it has work left
-    template <bool ANY>
-    __device__ inline bool vote_step(const SceneDev &sc, TraceStack &st, LaneCounters &cnt) {
+    template <bool ANY, class Stack>
+    __device__ inline bool vote_step(const SceneDev &sc, Stack &st, LaneCounters &cnt) {
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -242,8 +247,8 @@ struct Traversal {
 // One ray per lane, all lanes of the wave that reach the call together (`active` = false for
 // lanes with nothing to trace); returns when every lane's ray is finished.  tmax is updated to
 // the hit distance on closest hits.
-template <bool ANY>
-__device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, TraceStack &st, LaneCounters &cnt) {
+template <bool ANY, class Stack>
+__device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, Stack &st, LaneCounters &cnt) {
     Traversal t;
     if (active) t.begin(sc, ow, dw, tmin, tmax, cnt);
     while (t.vote_step<ANY>(sc, st, cnt)) {}

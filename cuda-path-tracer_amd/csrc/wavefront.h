@@ -27,17 +27,16 @@ struct WavefrontBuffers {
     float4 *sh_o;           // shadow ray origin.xyz | tmax
     float4 *sh_d;           // shadow ray direction.xyz | 1 when the path ends after this ray
     float4 *pending;        // light contribution added when the shadow ray is unoccluded
-    uint32_t *queue;        // per segment: ids of the paths whose next ray waits to be traced, packed at the segment's start
-    uint32_t *shadow_queue; // per segment: ids of the paths with a shadow ray
-    uint32_t *seg_count;    // entries of each segment's part of `queue`
-    uint32_t *shadow_count; // same for `shadow_queue`
+    uint32_t *queue;        // per segment: ids of the paths whose next ray waits to be traced, packed at the front, kNoEntry behind
+    uint32_t *shadow_queue; // per segment: ids of the paths with a shadow ray, same layout
     uint32_t *control;      // kControlWords words: fetch cursors + live marker
     uint32_t capacity;      // multiple of kSegmentSlots
     uint32_t segments;
 };
 
 size_t wavefront_slots(uint32_t width, uint32_t height);
-int wavefront_resident_blocks(int device);
+int wavefront_resident_blocks(int device);          // workgroups of a queue traversal kernel the device holds at once
+int wavefront_finish_resident_blocks(int device);   // same for the finishing kernel
 // camera rays + fresh path state for sample p.spp; fills the queue
 int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, hipStream_t stream);
 // one bounce: extend the queued rays, shade (refills the queue and the shadow queue), trace shadow

@@ -24,15 +24,12 @@ constexpr uint32_t kPrimaryBit = 0x80000000u;
 constexpr uint32_t kSpecularBit = 0x40000000u;
 constexpr uint32_t kPixelMask = 0x3fffffffu;
 constexpr int kRefillIdleLanes = 16;       // refill as soon as this many lanes of a wave are idle
-
-// packs the flagged lanes' values at the start of the wave's segment; one wave = one segment
-__device__ inline uint32_t segment_publish(uint32_t *queue, uint32_t *counts, uint32_t seg, bool flag, uint32_t value) {
-    const unsigned long long m = __ballot(flag);
-    const uint32_t lane = threadIdx.x & 63;
-    if (flag) queue[seg * kSegmentSlots + __popcll(m & ((1ull << lane) - 1ull))] = value;
-    if (lane == 0) counts[seg] = (uint32_t)__popcll(m);
-    return (uint32_t)__popcll(m);
-}
+// Waves per SIMD and LDS stack entries per lane of the queue traversal kernels.  They keep no path
+// state in registers and would fit 6 waves per SIMD with 12 entries (24 KB per workgroup), but
+// measured on cornell-box-glass that is slower (311 vs ~200 us per closest-hit pass over 1M rays):
+// the traversal is not limited by latency that more resident waves could hide.
+constexpr int kQueueTraceWaves = 4;
+constexpr int kQueueTraceLdsEntries = 16;
 
 // one lane per pixel slot (8x8 tiles): camera ray + fresh path state, src/kernels/integrator/path.cu:86-96
 __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
@@ -52,7 +49,7 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
         wb.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(0u));
         wb.col[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (tile < wb.segments) segment_publish(wb.queue, wb.seg_count, tile, valid, slot);
+    if (tile < wb.segments) segment_publish(wb.queue, tile, valid, slot);
     flush_counters(sc, LaneCounters{}, valid ? 1u : 0u, s_cnt);
 }
 
@@ -61,21 +58,20 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
 // light contribution to the path's colour, and a path that was only waiting for this ray is
 // written to the film.
 template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
-    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+__global__ void __launch_bounds__(kTraceBlock, kQueueTraceWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+    __shared__ uint2 s_stack[kQueueTraceLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
+    TraceStackT<kQueueTraceLdsEntries> st;
     st.lds = s_stack;
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t *queue = ANY ? wb.shadow_queue : wb.queue;
-    const uint32_t *counts = ANY ? wb.shadow_count : wb.seg_count;
     uint32_t *cursors = wb.control + (ANY ? kControlShadowCursors : kControlExtendCursors);
     // the shadow pass of the previous bounce is over, the one of this bounce has not begun
     if (!ANY) zero_cursors(wb.control + kControlShadowCursors);
 
-    SegmentFetch f;
+    SegmentFetchT<true> f;
     Traversal t;
     bool have = false;
     uint32_t path = 0;
@@ -83,11 +79,12 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, Render
         unsigned long long idle = __ballot(!have);
         if (!f.exhausted && (__popcll(idle) >= kRefillIdleLanes || idle == ~0ull)) {
             while (idle != 0ull) {
-                if (f.next >= f.end && !f.advance(counts, cursors, wb.segments, blockIdx.x, lane)) break;
+                if (f.remaining() == 0 && !f.advance(queue, cursors, wb.segments, blockIdx.x, lane)) break;
                 const uint32_t rank = __popcll(idle & lt_mask);
-                const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
+                const uint32_t take = min((uint32_t)__popcll(idle), f.remaining());
+                const uint32_t entry = f.entry(rank);
                 if (!have && rank < take) {
-                    path = queue[f.next + rank];
+                    path = entry;
                     if (ANY) {
                         float4 o = wb.sh_o[path], d = wb.sh_d[path];
                         t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, o.w, cnt);
@@ -97,7 +94,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_trace(SceneDev sc, Render
                     }
                     have = true;
                 }
-                f.next += take;
+                f.consumed += take;
                 idle = __ballot(!have);
             }
         }
@@ -131,11 +128,10 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
     zero_cursors(wb.control + kControlExtendCursors);       // the extend pass of this bounce is over
     const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg < wb.segments) {
-        const bool valid = lane < wb.seg_count[seg];
+        uint32_t path = wb.queue[seg * kSegmentSlots + lane];
+        const bool valid = path != kNoEntry;
         bool cont = false, need_shadow = false;
-        uint32_t path = 0;
         if (valid) {
-            path = wb.queue[seg * kSegmentSlots + lane];
             float4 fo = wb.ray_o[path], fd = wb.ray_d[path], ft = wb.thr[path], fc = wb.col[path], fh = wb.hit[path];
             uint32_t tag = __float_as_uint(fo.w);
             const uint32_t pixel_index = tag & kPixelMask;
@@ -227,8 +223,8 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
             if (finish && !need_shadow) film_accumulate(p, pixel_index, color);
         }
         // every lane has read its entry of the old list by now (one wave, program order)
-        const uint32_t live = segment_publish(wb.queue, wb.seg_count, seg, cont, path);
-        segment_publish(wb.shadow_queue, wb.shadow_count, seg, need_shadow, path);
+        const uint32_t live = segment_publish(wb.queue, seg, cont, path);
+        segment_publish(wb.shadow_queue, seg, need_shadow, path);
         if (live != 0 && lane == 0) wb.control[kControlLiveMarker] = bounce_id;    // same value from every wave
     }
     flush_counters(sc, cnt, 0u, s_cnt);
@@ -245,16 +241,16 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, Rende
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t *cursors = wb.control + kControlFinishCursors;
-    SegmentFetch f;
+    SegmentFetchT<false> f;
     PathLane l;
     for (;;) {
         unsigned long long idle = __ballot(!l.alive);
         while (idle != 0ull && !f.exhausted) {
-            if (f.next >= f.end && !f.advance(wb.seg_count, cursors, wb.segments, blockIdx.x, lane)) break;
+            if (f.remaining() == 0 && !f.advance(wb.queue, cursors, wb.segments, blockIdx.x, lane)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
-            const uint32_t take = min((uint32_t)__popcll(idle), f.end - f.next);
+            const uint32_t take = min((uint32_t)__popcll(idle), f.remaining());
+            const uint32_t path = f.entry(rank);
             if (!l.alive && rank < take) {
-                const uint32_t path = wb.queue[f.next + rank];
                 const float4 fo = wb.ray_o[path], fd = wb.ray_d[path], ft = wb.thr[path], fc = wb.col[path];
                 const uint32_t tag = __float_as_uint(fo.w);
                 l.alive = true;
@@ -267,7 +263,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, Rende
                 l.ro = v3(fo.x, fo.y, fo.z); l.rd = v3(fd.x, fd.y, fd.z);
                 l.throughput = v3(ft.x, ft.y, ft.z); l.color = v3(fc.x, fc.y, fc.z);
             }
-            f.next += take;
+            f.consumed += take;
             idle = __ballot(!l.alive);
         }
         if (__ballot(l.alive) == 0ull) break;
@@ -280,16 +276,25 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, Rende
 
 size_t wavefront_slots(uint32_t width, uint32_t height) { return (size_t)((width + 7) / 8) * ((height + 7) / 8) * kSegmentSlots; }
 
-int wavefront_resident_blocks(int device) {
+static int resident_blocks_of(const void *const *kernels, int count, int device) {
     int best = 1 << 30, cus = 0;
-    const void *kernels[3] = {(const void *)k_wf_trace<false>, (const void *)k_wf_trace<true>, (const void *)k_wf_finish};
-    for (const void *k : kernels) {
+    for (int i = 0; i < count; i++) {
         int a = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k, kTraceBlock, 0) != hipSuccess || a < 1) a = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, kernels[i], kTraceBlock, 0) != hipSuccess || a < 1) a = 1;
         if (a < best) best = a;
     }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return best * cus;
+}
+
+int wavefront_resident_blocks(int device) {
+    const void *kernels[2] = {(const void *)k_wf_trace<false>, (const void *)k_wf_trace<true>};
+    return resident_blocks_of(kernels, 2, device);
+}
+
+int wavefront_finish_resident_blocks(int device) {
+    const void *kernels[1] = {(const void *)k_wf_finish};
+    return resident_blocks_of(kernels, 1, device);
 }
 
 static uint32_t persistent_blocks(const WavefrontBuffers &wb, uint32_t resident_blocks) {
