@@ -59,6 +59,8 @@ _sig("cpt_scene_set_camera", C.c_int, [_vp, _f32, _f32, _f32, C.c_float, C.c_uin
 _sig("cpt_scene_num_objects", C.c_uint32, [_vp])
 _sig("cpt_scene_object_info", C.c_int, [_vp, C.c_uint32, C.c_char_p, C.c_size_t, _vp, _vp, _vp, _vp])
 _sig("cpt_scene_object_copy", C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp])
+_sig("cpt_scene_object_set_trs", C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp])
+_sig("cpt_scene_object_transforms", C.c_int, [_vp, C.c_uint32, _vp, _vp])
 _sig("cpt_scene_camera", C.c_int, [_vp, _vp, _vp])
 _sig("cpt_tracer_create", _vp, [_vp, C.c_uint32, C.c_uint32])
 _sig("cpt_tracer_destroy", None, [_vp])
@@ -232,6 +234,17 @@ class Scene:
 
     def objects(self):
         return [self.object(i) for i in range(self.num_objects())]
+
+    def set_trs(self, index, translate, rotate_degrees, scale):
+        t, r, s = (np.ascontiguousarray(v, dtype=np.float32) for v in (translate, rotate_degrees, scale))
+        check(lib.cpt_scene_object_set_trs(self.h, index, t.ctypes.data, r.ctypes.data, s.ctypes.data))
+        return self
+
+    def object_transforms(self, index):
+        m = np.zeros(16, dtype=np.float32)
+        inv = np.zeros(16, dtype=np.float32)
+        check(lib.cpt_scene_object_transforms(self.h, index, m.ctypes.data, inv.ctypes.data))
+        return m, inv
 
     def camera(self):
         cam = np.zeros(10, dtype=np.float32)

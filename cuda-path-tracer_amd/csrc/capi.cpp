@@ -265,6 +265,28 @@ int cpt_scene_object_info(const cpt_scene *s, uint32_t index, char *name_buf, si
     return CPT_OK;
 }
 
+int cpt_scene_object_set_trs(cpt_scene *s, uint32_t index, const float translate[3], const float rotate_degrees[3], const float scale[3]) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_set_trs: no such object");
+    if (!translate || !rotate_degrees || !scale) return Fail(CPT_ERR_INVALID, "cpt_scene_object_set_trs: null argument");
+    obj->translate = cpt::V3{translate[0], translate[1], translate[2]};
+    obj->rotate = cpt::V3{rotate_degrees[0], rotate_degrees[1], rotate_degrees[2]};
+    obj->scale = cpt::V3{scale[0], scale[1], scale[2]};
+    return CPT_OK;
+}
+
+int cpt_scene_object_transforms(const cpt_scene *s, uint32_t index, float transform16[16], float inverse16[16]) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_transforms: no such object");
+    const cpt::M4 t = obj->GetTransform();
+    if (transform16) memcpy(transform16, &t, 64);
+    if (inverse16) {
+        const cpt::M4 inv = InverseTransform(t);
+        memcpy(inverse16, &inv, 64);
+    }
+    return CPT_OK;
+}
+
 int cpt_scene_object_copy(const cpt_scene *s, uint32_t index, float *positions, float *normals, float *texcoords, uint32_t *indices) {
     SceneObject *obj = s ? MeshObject(s, index) : nullptr;
     if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_copy: no such object");

@@ -1,3 +1,4 @@
+#include <array>
 #include "scene.hpp"
 
 #include <cmath>
@@ -67,35 +68,94 @@ void Mesh::CalcTexcoords() {
 bool Material::IsEmissive() const { return cpt::dot(emission, emission) > 0.0f; }
 
 // ---------------------------------------------------------------- SceneObject / Scene
+// The reference composes object transforms with glm 0.9.9.8 in fp32 and the traversal multiplies
+// rays by the result, so the operation order of each glm routine is kept: a matrix that differs
+// in the last bit moves hits.
 namespace {
-M4 matmul(const M4 &a, const M4 &b) {
-    M4 r;
-    for (int c = 0; c < 4; c++) r.c[c] = cpt::mul(a, b.c[c]);
-    return r;
+using Cols = std::array<V4, 4>;
+
+V4 axpy3(const Cols &m, float a, float b, float c) {     // m[0]*a + m[1]*b + m[2]*c, left to right
+    return m[0] * a + m[1] * b + m[2] * c;
 }
-M4 rotation(float degrees, V3 axis) {
-    float a = degrees * 0.01745329251994329576923690768489f;
-    float c = std::cos(a), s = std::sin(a);
-    V3 t = axis * (1.0f - c);
-    M4 r = cpt::identity();
-    r.c[0] = V4{c + t.x * axis.x, t.x * axis.y + s * axis.z, t.x * axis.z - s * axis.y, 0.0f};
-    r.c[1] = V4{t.y * axis.x - s * axis.z, c + t.y * axis.y, t.y * axis.z + s * axis.x, 0.0f};
-    r.c[2] = V4{t.z * axis.x + s * axis.y, t.z * axis.y - s * axis.x, c + t.z * axis.z, 0.0f};
-    return r;
+
+// glm::translate, thirdparty/glm/glm/ext/matrix_transform.inl:9-15
+void Translate(Cols &m, V3 v) { m[3] = axpy3(m, v.x, v.y, v.z) + m[3]; }
+
+// glm::rotate about a coordinate axis, matrix_transform.inl:17-47 (normalize() of a unit axis is exact)
+void Rotate(Cols &m, float degrees, int axis_index) {
+    const float angle = degrees * static_cast<float>(0.01745329251994329576923690768489);    // glm::radians
+    const float c = std::cos(angle), s = std::sin(angle);
+    float axis[3] = {0.0f, 0.0f, 0.0f};
+    axis[axis_index] = 1.0f;
+    const float inv_len = cpt::inversesqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    for (float &a : axis) a = a * inv_len;
+    float temp[3];
+    for (int i = 0; i < 3; i++) temp[i] = (1.0f - c) * axis[i];
+    float rot[3][3];
+    rot[0][0] = c + temp[0] * axis[0];
+    rot[0][1] = temp[0] * axis[1] + s * axis[2];
+    rot[0][2] = temp[0] * axis[2] - s * axis[1];
+    rot[1][0] = temp[1] * axis[0] - s * axis[2];
+    rot[1][1] = c + temp[1] * axis[1];
+    rot[1][2] = temp[1] * axis[2] + s * axis[0];
+    rot[2][0] = temp[2] * axis[0] + s * axis[1];
+    rot[2][1] = temp[2] * axis[1] - s * axis[0];
+    rot[2][2] = c + temp[2] * axis[2];
+    const Cols in = m;
+    for (int i = 0; i < 3; i++) m[i] = axpy3(in, rot[i][0], rot[i][1], rot[i][2]);
 }
+
+// glm::scale, matrix_transform.inl:77-85
+void Scale(Cols &m, V3 v) { m[0] = m[0] * v.x; m[1] = m[1] * v.y; m[2] = m[2] * v.z; }
 }  // namespace
 
 M4 SceneObject::GetTransform() const {            // src/scene/core.cpp:109-117
-    M4 trans = cpt::identity();
-    M4 t = cpt::identity();
-    t.c[3] = V4{translate.x, translate.y, translate.z, 1.0f};
-    trans = matmul(trans, t);
-    trans = matmul(trans, rotation(rotate.z, V3{0.0f, 0.0f, 1.0f}));
-    trans = matmul(trans, rotation(rotate.y, V3{0.0f, 1.0f, 0.0f}));
-    trans = matmul(trans, rotation(rotate.x, V3{1.0f, 0.0f, 0.0f}));
-    M4 s = cpt::identity();
-    s.c[0].x = scale.x; s.c[1].y = scale.y; s.c[2].z = scale.z;
-    return matmul(trans, s);
+    const M4 id = cpt::identity();
+    Cols m = {id.c[0], id.c[1], id.c[2], id.c[3]};
+    Translate(m, translate);
+    Rotate(m, rotate.z, 2);
+    Rotate(m, rotate.y, 1);
+    Rotate(m, rotate.x, 0);
+    Scale(m, scale);
+    M4 out;
+    for (int i = 0; i < 4; i++) out.c[i] = m[i];
+    return out;
+}
+
+// glm::inverse(mat4), thirdparty/glm/glm/detail/func_matrix.inl:294-352, which is what
+// src/pathtracer/pathtracer.cpp:113 stores next to the transform: eighteen 2x2 minors of the lower
+// rows, cofactor columns with alternating signs, determinant from the first column, everything in
+// fp32 in glm's order.
+M4 InverseTransform(const M4 &mat) {
+    float m[4][4];      // m[column][row]
+    for (int c = 0; c < 4; c++) { m[c][0] = mat.c[c].x; m[c][1] = mat.c[c].y; m[c][2] = mat.c[c].z; m[c][3] = mat.c[c].w; }
+    auto minor2 = [&m](int ca, int ra, int cb, int rb) { return m[ca][ra] * m[cb][rb] - m[cb][ra] * m[ca][rb]; };
+    // coef[g] = {minor of columns (2,3), (1,3), (1,2)} for the row pair of group g
+    static const int kRows[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+    float fac[6][4];
+    for (int g = 0; g < 6; g++) {
+        const int ra = kRows[g][0], rb = kRows[g][1];
+        const float c23 = minor2(2, ra, 3, rb), c13 = minor2(1, ra, 3, rb), c12 = minor2(1, ra, 2, rb);
+        fac[g][0] = c23; fac[g][1] = c23; fac[g][2] = c13; fac[g][3] = c12;
+    }
+    float vec[4][4];
+    for (int r = 0; r < 4; r++) { vec[r][0] = m[1][r]; vec[r][1] = m[0][r]; vec[r][2] = m[0][r]; vec[r][3] = m[0][r]; }
+    // column k of the adjugate: the three rows other than k, against the three factor groups that do not involve row k
+    static const int kTerms[4][3][2] = {{{1, 0}, {2, 1}, {3, 2}}, {{0, 0}, {2, 3}, {3, 4}}, {{0, 1}, {1, 3}, {3, 5}}, {{0, 2}, {1, 4}, {2, 5}}};
+    float inv[4][4];
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 4; j++) {
+            const float a = vec[kTerms[k][0][0]][j] * fac[kTerms[k][0][1]][j];
+            const float b = vec[kTerms[k][1][0]][j] * fac[kTerms[k][1][1]][j];
+            const float c = vec[kTerms[k][2][0]][j] * fac[kTerms[k][2][1]][j];
+            const float sign = ((k + j) & 1) ? -1.0f : 1.0f;
+            inv[k][j] = (a - b + c) * sign;
+        }
+    const float d0 = m[0][0] * inv[0][0], d1 = m[0][1] * inv[1][0], d2 = m[0][2] * inv[2][0], d3 = m[0][3] * inv[3][0];
+    const float one_over_det = 1.0f / ((d0 + d1) + (d2 + d3));
+    M4 out;
+    for (int c = 0; c < 4; c++) out.c[c] = V4{inv[c][0] * one_over_det, inv[c][1] * one_over_det, inv[c][2] * one_over_det, inv[c][3] * one_over_det};
+    return out;
 }
 
 std::shared_ptr<SceneObject> Scene::AddObject(std::string_view name) {

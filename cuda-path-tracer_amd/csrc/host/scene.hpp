@@ -99,6 +99,9 @@ public:
 
 class PathTracer;
 
+// inverse of an object transform exactly as glm::inverse computes it (src/pathtracer/pathtracer.cpp:113)
+cpt::M4 InverseTransform(const cpt::M4 &mat);
+
 // One scene object with at most one component of each kind (the reference's block-list ECS,
 // src/scene/core.hpp:13-110, is an implementation detail; iteration order = insertion order).
 class SceneObject {

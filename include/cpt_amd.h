@@ -84,6 +84,13 @@ int cpt_scene_add_object(cpt_scene *s, const char *name, const float *positions,
                          const float *transform16);
 int cpt_scene_set_camera(cpt_scene *s, const float pos[3], const float look_at[3], const float up[3], float fov_degrees,
                          uint32_t film_width, uint32_t film_height);
+/* SceneObject::translate / rotate (degrees, applied as Rz * Ry * Rx) / scale of mesh object `index`
+ * (src/scene/core.hpp:232-234); the transform is T * Rz * Ry * Rx * S (src/scene/core.cpp:109-117).
+ * Takes effect at the next cpt_tracer_build_buffers. */
+int cpt_scene_object_set_trs(cpt_scene *s, uint32_t index, const float translate[3], const float rotate_degrees[3], const float scale[3]);
+/* the object's transform and the inverse the path tracer stores with it (src/pathtracer/pathtracer.cpp:110-114),
+ * column major; either pointer may be NULL */
+int cpt_scene_object_transforms(const cpt_scene *s, uint32_t index, float transform16[16], float inverse16[16]);
 /* introspection (used by the parity tests to feed the same arrays to the CPU oracle) */
 uint32_t cpt_scene_num_objects(const cpt_scene *s);                 /* objects that carry a mesh */
 int cpt_scene_object_info(const cpt_scene *s, uint32_t index, char *name_buf, size_t name_buf_size, uint32_t *num_vertices,

@@ -91,35 +91,88 @@ inline M4 transpose(const M4 &m) {
     r.c[3] = {m.c[0].w, m.c[1].w, m.c[2].w, m.c[3].w};
     return r;
 }
-// general 4x4 inverse by cofactors (host side only; identity for every shipped scene)
-M4 inverse(const M4 &mm) {
-    const float *m = &mm.c[0].x;
-    double inv[16], a[16];
-    for (int i = 0; i < 16; i++) a[i] = m[i];
-    inv[0] = a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
-    inv[4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
-    inv[8] = a[4]*a[9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[9];
-    inv[12] = -a[4]*a[9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[9];
-    inv[1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
-    inv[5] = a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
-    inv[9] = -a[0]*a[9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[9];
-    inv[13] = a[0]*a[9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[9];
-    inv[2] = a[1]*a[6]*a[15] - a[1]*a[7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[7] - a[13]*a[3]*a[6];
-    inv[6] = -a[0]*a[6]*a[15] + a[0]*a[7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[7] + a[12]*a[3]*a[6];
-    inv[10] = a[0]*a[5]*a[15] - a[0]*a[7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[7] - a[12]*a[3]*a[5];
-    inv[14] = -a[0]*a[5]*a[14] + a[0]*a[6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[6] + a[12]*a[2]*a[5];
-    inv[3] = -a[1]*a[6]*a[11] + a[1]*a[7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[9]*a[2]*a[7] + a[9]*a[3]*a[6];
-    inv[7] = a[0]*a[6]*a[11] - a[0]*a[7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[8]*a[2]*a[7] - a[8]*a[3]*a[6];
-    inv[11] = -a[0]*a[5]*a[11] + a[0]*a[7]*a[9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[9] - a[8]*a[1]*a[7] + a[8]*a[3]*a[5];
-    inv[15] = a[0]*a[5]*a[10] - a[0]*a[6]*a[9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[9] + a[8]*a[1]*a[6] - a[8]*a[2]*a[5];
-    double det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
-    M4 r;
-    float *o = &r.c[0].x;
-    for (int i = 0; i < 16; i++) {
-        double v = inv[i] / det;
-        o[i] = (v == 0.0) ? 0.0f : (float)v;   // no negative zeros
-    }
+inline V4 operator-(V4 a, V4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline V4 operator*(V4 a, V4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline float elem(const M4 &m, int col, int row) { return (&m.c[col].x)[row]; }
+
+// glm::inverse(mat4), thirdparty/glm/glm/detail/func_matrix.inl:294-352: 2x2 sub-determinants,
+// four cofactor columns with alternating signs, determinant from the first column, all in fp32
+M4 inverse(const M4 &m) {
+    float c00 = elem(m, 2, 2) * elem(m, 3, 3) - elem(m, 3, 2) * elem(m, 2, 3);
+    float c02 = elem(m, 1, 2) * elem(m, 3, 3) - elem(m, 3, 2) * elem(m, 1, 3);
+    float c03 = elem(m, 1, 2) * elem(m, 2, 3) - elem(m, 2, 2) * elem(m, 1, 3);
+    float c04 = elem(m, 2, 1) * elem(m, 3, 3) - elem(m, 3, 1) * elem(m, 2, 3);
+    float c06 = elem(m, 1, 1) * elem(m, 3, 3) - elem(m, 3, 1) * elem(m, 1, 3);
+    float c07 = elem(m, 1, 1) * elem(m, 2, 3) - elem(m, 2, 1) * elem(m, 1, 3);
+    float c08 = elem(m, 2, 1) * elem(m, 3, 2) - elem(m, 3, 1) * elem(m, 2, 2);
+    float c10 = elem(m, 1, 1) * elem(m, 3, 2) - elem(m, 3, 1) * elem(m, 1, 2);
+    float c11 = elem(m, 1, 1) * elem(m, 2, 2) - elem(m, 2, 1) * elem(m, 1, 2);
+    float c12 = elem(m, 2, 0) * elem(m, 3, 3) - elem(m, 3, 0) * elem(m, 2, 3);
+    float c14 = elem(m, 1, 0) * elem(m, 3, 3) - elem(m, 3, 0) * elem(m, 1, 3);
+    float c15 = elem(m, 1, 0) * elem(m, 2, 3) - elem(m, 2, 0) * elem(m, 1, 3);
+    float c16 = elem(m, 2, 0) * elem(m, 3, 2) - elem(m, 3, 0) * elem(m, 2, 2);
+    float c18 = elem(m, 1, 0) * elem(m, 3, 2) - elem(m, 3, 0) * elem(m, 1, 2);
+    float c19 = elem(m, 1, 0) * elem(m, 2, 2) - elem(m, 2, 0) * elem(m, 1, 2);
+    float c20 = elem(m, 2, 0) * elem(m, 3, 1) - elem(m, 3, 0) * elem(m, 2, 1);
+    float c22 = elem(m, 1, 0) * elem(m, 3, 1) - elem(m, 3, 0) * elem(m, 1, 1);
+    float c23 = elem(m, 1, 0) * elem(m, 2, 1) - elem(m, 2, 0) * elem(m, 1, 1);
+    V4 fac0{c00, c00, c02, c03}, fac1{c04, c04, c06, c07}, fac2{c08, c08, c10, c11};
+    V4 fac3{c12, c12, c14, c15}, fac4{c16, c16, c18, c19}, fac5{c20, c20, c22, c23};
+    V4 vec0{elem(m, 1, 0), elem(m, 0, 0), elem(m, 0, 0), elem(m, 0, 0)};
+    V4 vec1{elem(m, 1, 1), elem(m, 0, 1), elem(m, 0, 1), elem(m, 0, 1)};
+    V4 vec2{elem(m, 1, 2), elem(m, 0, 2), elem(m, 0, 2), elem(m, 0, 2)};
+    V4 vec3{elem(m, 1, 3), elem(m, 0, 3), elem(m, 0, 3), elem(m, 0, 3)};
+    V4 inv0 = vec1 * fac0 - vec2 * fac1 + vec3 * fac2;
+    V4 inv1 = vec0 * fac0 - vec2 * fac3 + vec3 * fac4;
+    V4 inv2 = vec0 * fac1 - vec1 * fac3 + vec3 * fac5;
+    V4 inv3 = vec0 * fac2 - vec1 * fac4 + vec2 * fac5;
+    V4 sign_a{+1.0f, -1.0f, +1.0f, -1.0f}, sign_b{-1.0f, +1.0f, -1.0f, +1.0f};
+    M4 inv;
+    inv.c[0] = inv0 * sign_a; inv.c[1] = inv1 * sign_b; inv.c[2] = inv2 * sign_a; inv.c[3] = inv3 * sign_b;
+    V4 row0{inv.c[0].x, inv.c[1].x, inv.c[2].x, inv.c[3].x};
+    V4 dot0 = m.c[0] * row0;
+    float dot1 = (dot0.x + dot0.y) + (dot0.z + dot0.w);
+    float one_over_det = 1.0f / dot1;
+    for (int i = 0; i < 4; i++) inv.c[i] = inv.c[i] * one_over_det;
+    return inv;
+}
+
+inline M4 identity() { return M4{{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}}; }
+
+// glm::translate / rotate / scale, thirdparty/glm/glm/ext/matrix_transform.inl:9-57, :77-85
+M4 translate(const M4 &m, V3 v) {
+    M4 r = m;
+    r.c[3] = m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z + m.c[3];
     return r;
+}
+M4 rotate(const M4 &m, float angle, V3 v) {
+    float c = std::cos(angle), s = std::sin(angle);
+    V3 axis = normalize(v);
+    V3 temp = (1.0f - c) * axis;
+    float r00 = c + temp.x * axis.x, r01 = temp.x * axis.y + s * axis.z, r02 = temp.x * axis.z - s * axis.y;
+    float r10 = temp.y * axis.x - s * axis.z, r11 = c + temp.y * axis.y, r12 = temp.y * axis.z + s * axis.x;
+    float r20 = temp.z * axis.x + s * axis.y, r21 = temp.z * axis.y - s * axis.x, r22 = c + temp.z * axis.z;
+    M4 r;
+    r.c[0] = m.c[0] * r00 + m.c[1] * r01 + m.c[2] * r02;
+    r.c[1] = m.c[0] * r10 + m.c[1] * r11 + m.c[2] * r12;
+    r.c[2] = m.c[0] * r20 + m.c[1] * r21 + m.c[2] * r22;
+    r.c[3] = m.c[3];
+    return r;
+}
+M4 scale(const M4 &m, V3 v) {
+    M4 r;
+    r.c[0] = m.c[0] * v.x; r.c[1] = m.c[1] * v.y; r.c[2] = m.c[2] * v.z; r.c[3] = m.c[3];
+    return r;
+}
+// SceneObject::GetTransform, src/scene/core.cpp:109-117 (glm::radians: func_trigonometric.inl:9-14)
+M4 trs_matrix(V3 t, V3 r_deg, V3 s) {
+    const float to_rad = static_cast<float>(0.01745329251994329576923690768489);
+    M4 m = identity();
+    m = translate(m, t);
+    m = rotate(m, r_deg.z * to_rad, V3{0.0f, 0.0f, 1.0f});
+    m = rotate(m, r_deg.y * to_rad, V3{0.0f, 1.0f, 0.0f});
+    m = rotate(m, r_deg.x * to_rad, V3{1.0f, 0.0f, 0.0f});
+    return scale(m, s);
 }
 
 constexpr float kPi = 3.14159265359f;          // basic/prelude.cuh:19-22
@@ -1188,6 +1241,15 @@ int orc_scene_add_instance(void *h, int mesh, const float *transform_colmajor16,
     mt.shininess = mat16[12]; mt.ior = mat16[13]; mt.opacity = mat16[14]; mt.bsdf_type = (int)mat16[15];
     sc.instances.push_back(inst);
     return (int)sc.instances.size() - 1;
+}
+
+// object transform from translate / rotate (degrees) / scale, and its inverse as the path tracer
+// stores it (src/scene/core.cpp:109-117, src/pathtracer/pathtracer.cpp:112-114); column major
+void orc_trs_matrix(const float *t3, const float *r3, const float *s3, float *out16, float *out_inv16) {
+    M4 m = trs_matrix(V3{t3[0], t3[1], t3[2]}, V3{r3[0], r3[1], r3[2]}, V3{s3[0], s3[1], s3[2]});
+    M4 inv = inverse(m);
+    std::memcpy(out16, &m, 64);
+    std::memcpy(out_inv16, &inv, 64);
 }
 
 // src/scene/camera.cpp:28-50

@@ -24,6 +24,7 @@
 #include <limits>
 #include <vector>
 
+#include <glm/gtc/matrix_transform.hpp>   // glm::translate / rotate / scale, as src/scene/core.cpp includes them
 #include "kernels/accel/accel.cuh"
 #include "kernels/bsdf/bsdf.cuh"
 #include "kernels/sampler/sampler.cuh"
@@ -91,6 +92,21 @@ int ref_scene_add_mesh(void *h, const float *pos, const float *nrm, const float 
     m->accel.geometry.ptr = &m->trimesh;
     sc.meshes.push_back(m);
     return (int)sc.meshes.size() - 1;
+}
+
+// SceneObject::GetTransform (src/scene/core.cpp:109-117) and the inverse PathTracer::BuildAccel
+// stores with it (src/pathtracer/pathtracer.cpp:112-114), through the reference's own glm
+void ref_trs_matrix(const float *t3, const float *r3, const float *s3, float *out16, float *out_inv16) {
+    glm::vec3 translate(t3[0], t3[1], t3[2]), rotate(r3[0], r3[1], r3[2]), scale(s3[0], s3[1], s3[2]);
+    glm::mat4 trans(1.0f);
+    trans = glm::translate(trans, translate);
+    trans = glm::rotate(trans, glm::radians(rotate.z), glm::vec3(0.0f, 0.0f, 1.0f));
+    trans = glm::rotate(trans, glm::radians(rotate.y), glm::vec3(0.0f, 1.0f, 0.0f));
+    trans = glm::rotate(trans, glm::radians(rotate.x), glm::vec3(1.0f, 0.0f, 0.0f));
+    trans = glm::scale(trans, scale);
+    glm::mat4 inv = glm::inverse(trans);
+    memcpy(out16, &trans, 64);
+    memcpy(out_inv16, &inv, 64);
 }
 
 int ref_scene_add_instance(void *h, int mesh, const float *transform16, const float *transform_inv16) {

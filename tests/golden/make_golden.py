@@ -29,7 +29,8 @@ def ref_scene_from(osc, objects):
         nodes, boxes, _ = osc.accel(i)
         R.ref_scene_add_mesh(h, o["positions"].reshape(-1), o["normals"].reshape(-1), o["texcoords"].reshape(-1), len(o["positions"]),
                              o["indices"], len(o["indices"]) // 3, nodes.reshape(-1), boxes.reshape(-1))
-        R.ref_scene_add_instance(h, i, IDENTITY, IDENTITY)
+        m, inv = trs_matrix(R, "ref", o.get("trs", IDENTITY_TRS))     # the reference's own glm builds the matrices it traverses with
+        R.ref_scene_add_instance(h, i, m, inv)
     nodes, boxes, _ = osc.accel(-1)
     R.ref_scene_set_top(h, nodes.reshape(-1), boxes.reshape(-1))
     return h
@@ -127,6 +128,44 @@ def main():
     out["camera18"] = cam18
     out["camera_rays_24x24"] = ref_rays
     np.savez_compressed(os.path.join(HERE, "ref_traversal.npz"), **out)
+
+    # ---- object transforms: glm::translate/rotate/scale/inverse and traversal through them -------
+    rng = np.random.Generator(np.random.PCG64(77))
+    n_trs = 64
+    trs = np.zeros((n_trs, 9), np.float32)
+    trs[:, 0:3] = rng.uniform(-2, 2, (n_trs, 3))
+    trs[:, 3:6] = rng.uniform(-180, 180, (n_trs, 3))
+    trs[:, 6:9] = rng.uniform(0.25, 3.0, (n_trs, 3))
+    trs[0] = [0, 0, 0, 0, 0, 0, 1, 1, 1]
+    trs[1] = [1, -2, 3, 90, 0, 0, 1, 1, 1]
+    trs[2] = [0, 0, 0, 0, 180, 45, 2, 2, 2]
+    mats = np.zeros((n_trs, 2, 16), np.float32)
+    for k in range(n_trs):
+        rm, rinv = trs_matrix(R, "ref", (trs[k, 0:3], trs[k, 3:6], trs[k, 6:9]))
+        om, oinv = trs_matrix(L, "orc", (trs[k, 0:3], trs[k, 3:6], trs[k, 6:9]))
+        assert np.array_equal(rm.view(np.uint32), om.view(np.uint32)), "oracle object transform differs from glm"
+        assert np.array_equal(rinv.view(np.uint32), oinv.view(np.uint32)), "oracle matrix inverse differs from glm"
+        mats[k, 0], mats[k, 1] = rm, rinv
+    tout = dict(trs=trs, matrices=mats)
+    objs, cam = cornell_moved(glass=True)
+    osc = OracleScene(objs, cam)
+    h = ref_scene_from(osc, objs)
+    rays = np.concatenate([osc.camera_rays(96, 96, 1),
+                           interior_rays(6000, 21, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32))])
+    inst, prim, t, uv = ref_first_hit(h, rays)
+    o_inst, o_prim, o_t, o_uv, _ = osc.first_hit(rays)
+    assert np.array_equal(inst, o_inst) and np.array_equal(prim, o_prim), "oracle traversal of transformed instances differs from the reference"
+    assert np.array_equal(t.view(np.uint32), o_t.view(np.uint32)) and np.array_equal(uv, o_uv)
+    sh = rays[96 * 96:].copy()
+    sh[:, 7] = 0.9
+    occ = np.zeros(len(sh), np.uint8)
+    R.ref_occlude(h, sh, len(sh), occ)
+    assert np.array_equal(occ, osc.occlude(sh))
+    assert (inst[:96 * 96] == 5).any() and (inst[:96 * 96] == 7).any(), "camera sees both moved blocks"
+    tout.update(moved_rays=rays, moved_inst=inst.astype(np.int64).astype(np.int16), moved_prim=prim.astype(np.int64).astype(np.int16),
+                moved_t=t, moved_uv=uv, moved_occluded=occ)
+    R.ref_scene_destroy(h)
+    np.savez_compressed(os.path.join(HERE, "ref_transform.npz"), **tout)
 
     # ---- sampler ----------------------------------------------------------------------------
     xs = np.array([0, 1, 2, 255, 256, 65535, 262143, 1048575, 0x7fffffff, 0xffffffff], np.uint32)

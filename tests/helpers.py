@@ -65,6 +65,7 @@ def oracle():
     L.orc_material_bsdf.argtypes = [f32p, f32p]
     L.orc_mesh_vertex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float, f32p]
     L.orc_frame.argtypes = [f32p, f32p]
+    L.orc_trs_matrix.argtypes = [f32p, f32p, f32p, f32p, f32p]
     L.orc_luminance.restype = C.c_float
     L.orc_luminance.argtypes = [C.c_float, C.c_float, C.c_float]
     _oracle = L
@@ -101,6 +102,7 @@ def ref_lib():
     L.ref_bsdf_eval.argtypes = [C.c_int, f32p, f32p, f32p, f32p]
     L.ref_camera_ray.argtypes = [f32p, C.c_float, C.c_float, C.c_float, f32p]
     L.ref_frame.argtypes = [f32p, f32p]
+    L.ref_trs_matrix.argtypes = [f32p, f32p, f32p, f32p, f32p]
     L.ref_luminance.restype = C.c_float
     L.ref_luminance.argtypes = [C.c_float, C.c_float, C.c_float]
     _ref = L
@@ -248,6 +250,39 @@ def load_json_camera(path):
                 up=np.array(cam["up"], dtype=np.float32), fov=float(cam["fov"]), width=int(res[0]), height=int(res[1]))
 
 
+# glm::inverse of the identity has negative zeros off the diagonal; objects without a transform get that matrix too
+IDENTITY_TRS = ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+
+
+def trs_matrix(lib, prefix, trs):
+    """(transform16, inverse16), column major, from (translate, rotate in degrees, scale)."""
+    t, r, s = (np.ascontiguousarray(x, dtype=np.float32) for x in trs)
+    m = np.zeros(16, np.float32); inv = np.zeros(16, np.float32)
+    getattr(lib, prefix + "_trs_matrix")(t, r, s, m, inv)
+    return m, inv
+
+
+def object_transform(o):
+    """An object's transform and inverse by the oracle's restatement of SceneObject::GetTransform."""
+    return trs_matrix(oracle(), "orc", o.get("trs", IDENTITY_TRS))
+
+
+def cornell_moved(glass=True):
+    """The Cornell box with the two blocks and the light moved by object transforms: rotation about
+    all three axes, a non-uniform scale, a translation (SceneObject::translate/rotate/scale,
+    src/scene/core.hpp:177-240; the shipped scene files leave them at identity)."""
+    objs, cam = cornell(glass=glass)
+    by_name = {o["name"]: o for o in objs}
+    names = list(by_name)
+    tall = [n for n in names if "tall" in n.lower()][0]
+    short = [n for n in names if "short" in n.lower()][0]
+    light = [n for n in names if "light" in n.lower()][0]
+    by_name[tall]["trs"] = ([0.12, 0.0, -0.05], [0.0, 17.0, 4.0], [0.9, 1.15, 1.0])
+    by_name[short]["trs"] = ([-0.1, 0.05, 0.1], [8.0, -31.0, 0.0], [1.2, 0.8, 1.1])
+    by_name[light]["trs"] = ([0.05, -0.01, 0.0], [0.0, 30.0, 0.0], [0.8, 1.0, 0.8])
+    return objs, cam
+
+
 class OracleScene:
     """A scene inside the oracle, fed with flat arrays."""
 
@@ -258,7 +293,7 @@ class OracleScene:
         for o in objects:
             m = self.L.orc_scene_add_mesh(self.h, o["positions"], o["normals"], o["texcoords"], len(o["positions"]),
                                           o["indices"], len(o["indices"]) // 3)
-            self.L.orc_scene_add_instance(self.h, m, o.get("transform", IDENTITY), o["material"])
+            self.L.orc_scene_add_instance(self.h, m, object_transform(o)[0], o["material"])
         if camera is not None:
             self.L.orc_scene_set_camera(self.h, camera["pos"], camera["look_at"], camera["up"], camera["fov"])
         self.L.orc_scene_build(self.h)

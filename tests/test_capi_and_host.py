@@ -53,6 +53,25 @@ def test_obj_loader_matches_independent_reader(cpt, glass):
     assert c["fov"] == np.float32(19.5) and np.array_equal(c["pos"], cam["pos"])
 
 
+def test_object_transforms_match_glm_vectors(cpt):
+    """SceneObject::GetTransform and the stored inverse, bit for bit against matrices produced by
+    the reference's own glm (tests/golden/ref_transform.npz)."""
+    g = np.load(os.path.join(os.path.dirname(SCENES), "ref_transform.npz"))
+    objs, _ = cornell(glass=False)
+    o = objs[0]
+    sc = cpt.Scene().add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+    m, inv = sc.object_transforms(0)
+    assert np.array_equal(m, IDENTITY) and np.array_equal(inv, IDENTITY)
+    for k, row in enumerate(g["trs"]):
+        sc.set_trs(0, row[0:3], row[3:6], row[6:9])
+        m, inv = sc.object_transforms(0)
+        assert np.array_equal(m.view(np.uint32), g["matrices"][k, 0].view(np.uint32)), k
+        assert np.array_equal(inv.view(np.uint32), g["matrices"][k, 1].view(np.uint32)), k
+        assert np.array_equal(sc.object(0)["transform"], m)
+    with pytest.raises(cpt.CptError):
+        sc.set_trs(5, [0, 0, 0], [0, 0, 0], [1, 1, 1])
+
+
 def test_bsdf_type_flag_and_default_material(cpt, tmp_path):
     obj = tmp_path / "t.obj"
     obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 3/1/1 4/1/1\n")

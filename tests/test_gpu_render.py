@@ -46,6 +46,26 @@ def test_cornell_against_oracle(cpt, glass, depth, bsdf):
     assert abs(c["rays"] - int(ocnt[0])) <= 0.002 * int(ocnt[0])         # same paths up to a few flipped decisions
 
 
+def test_transformed_instances_render(cpt):
+    """Shading through object transforms: normals by the inverse transpose, the moved light's
+    sampling and pdf (instance.cuh:14-27, light/geometry.cuh:9-31), against the oracle."""
+    objs, cam = cornell_moved(glass=True)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=6)
+    tr.update(16)
+    img = tr.film()
+    ref, _ = osc.render(64, 64, 1, 17, 6)
+    err = np.linalg.norm(img[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
+    assert err <= REL_L2_TOL, err
+    assert np.abs(img[..., :3].mean(axis=(0, 1)) - ref[..., :3].mean(axis=(0, 1))).max() <= MEAN_TOL
+    tr.set_channel(1)
+    tr.reset()
+    tr.update(1)
+    nrm = tr.film()
+    ref_n, _ = osc.render(64, 64, 1, 2, 6, channel=1)
+    assert np.abs(nrm[..., :3] - ref_n[..., :3]).max() <= 1e-6
+
+
 def test_survey_statistics(cpt):
     d = os.path.join(SCENES, "cornell-box-glass")
     sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))

@@ -15,6 +15,8 @@ def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5):
     sc = cpt.Scene()
     for o in objects:
         sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+        if "trs" in o:
+            sc.set_trs(sc.num_objects() - 1, *o["trs"])
     sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], width, height)
     return sc, cpt.Tracer(sc, width, height, max_depth=max_depth).build_buffers()
 
@@ -71,6 +73,37 @@ def test_cornell_camera_and_interior_rays(cpt, glass):
     assert_same_hits(tr, osc, rays)
     sh = interior_rays(100000, 6, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32), tmax=0.9)
     assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
+
+
+def test_transformed_instances(cpt):
+    """Object transforms (rotation about three axes, non-uniform scale, translation): the top-level
+    boxes, TransformRay without renormalisation (accel.cuh:54-59) and hits inside the moved
+    instances, against the oracle and against vectors from the reference's own traversal + glm."""
+    objs, cam = cornell_moved(glass=True)
+    osc = OracleScene(objs, cam)
+    sc, tr = gpu_scene(cpt, objs, cam, 64, 64)
+    for i, o in enumerate(objs):
+        m, inv = sc.object_transforms(i)
+        om, oinv = object_transform(o)
+        assert np.array_equal(m.view(np.uint32), om.view(np.uint32)) and np.array_equal(inv.view(np.uint32), oinv.view(np.uint32))
+    nodes, boxes, keys = tr.accel(-1)
+    o_nodes, o_boxes, o_keys = osc.accel(-1)
+    assert np.array_equal(nodes, o_nodes) and np.array_equal(keys, o_keys)
+    assert np.array_equal(boxes.view(np.uint32), o_boxes.view(np.uint32))
+    g = np.load(os.path.join(GOLDEN, "ref_transform.npz"))
+    rays = g["moved_rays"]
+    inst, prim, t, uv = tr.first_hit(rays)
+    assert np.array_equal(inst.astype(np.int64).astype(np.int16), g["moved_inst"])
+    assert np.array_equal(prim.astype(np.int64).astype(np.int16), g["moved_prim"])
+    assert np.array_equal(t.view(np.uint32), g["moved_t"].view(np.uint32))
+    assert np.array_equal(uv, g["moved_uv"])
+    sh = rays[96 * 96:].copy()
+    sh[:, 7] = 0.9
+    assert np.array_equal(tr.occlude(sh), g["moved_occluded"])
+    big = interior_rays(300000, 9, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32))
+    o_inst, _ = assert_same_hits(tr, osc, big)
+    assert (o_inst == 5).any() and (o_inst == 7).any()
+    assert_same_hits(tr, osc, osc.camera_rays(512, 512, 3))
 
 
 def test_against_reference_vectors(cpt):

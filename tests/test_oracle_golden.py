@@ -102,6 +102,29 @@ def test_traversal_golden():
     assert np.array_equal(osc.camera_rays(24, 24, 1).view(np.uint32), g["camera_rays_24x24"].view(np.uint32))
 
 
+def test_object_transform_golden():
+    """translate/rotate/scale composition and matrix inverse against the reference's glm (vectors
+    from make_golden.py), and traversal through transformed instances."""
+    g = np.load(os.path.join(GOLDEN, "ref_transform.npz"))
+    L = oracle()
+    for k, row in enumerate(g["trs"]):
+        m, inv = trs_matrix(L, "orc", (row[0:3], row[3:6], row[6:9]))
+        assert np.array_equal(m.view(np.uint32), g["matrices"][k, 0].view(np.uint32)), k
+        assert np.array_equal(inv.view(np.uint32), g["matrices"][k, 1].view(np.uint32)), k
+    objs, cam = cornell_moved(glass=True)
+    osc = OracleScene(objs, cam)
+    rays = g["moved_rays"]
+    assert np.array_equal(osc.camera_rays(96, 96, 1).view(np.uint32), rays[:96 * 96].view(np.uint32))
+    inst, prim, t, uv, _ = osc.first_hit(rays)
+    assert np.array_equal(inst.astype(np.int64).astype(np.int16), g["moved_inst"])
+    assert np.array_equal(prim.astype(np.int64).astype(np.int16), g["moved_prim"])
+    assert np.array_equal(t.view(np.uint32), g["moved_t"].view(np.uint32))
+    assert np.array_equal(uv, g["moved_uv"])
+    sh = rays[96 * 96:].copy()
+    sh[:, 7] = 0.9
+    assert np.array_equal(osc.occlude(sh), g["moved_occluded"])
+
+
 def test_sampler_golden():
     g = np.load(os.path.join(GOLDEN, "ref_sampler.npz"))
     L = oracle()
