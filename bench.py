@@ -47,7 +47,8 @@ def algorithmic_bytes(c, pixels_per_launch, launches):
 
 def lbvh_timings(cpt, n, seed=12345, repeats=10):
     """Median device time of the whole build (Morton -> sort -> nodes -> refit) with buffers
-    pre-allocated, after two warm-ups; plus the per-stage split of one extra run."""
+    pre-allocated, after two warm-ups; plus the per-stage split of one extra run (hierarchy = leaf
+    gather + topology + boxes, two kernels)."""
     from helpers import random_soup, boxes_of_triangles
     soup = random_soup(n, seed=seed)
     boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
@@ -66,7 +67,8 @@ def lbvh_timings(cpt, n, seed=12345, repeats=10):
     cpt.check(cpt.lib.cpt_builder_build(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, None, stage.ctypes.data))
     cpt.lib.cpt_builder_destroy(b)
     med = float(np.median(times))
-    return dict(build_ms=round(med, 4), sort_ms=round(float(stage[1]), 4), refit_ms=round(float(stage[4]), 4),
+    return dict(build_ms=round(med, 4), morton_ms=round(float(stage[0]), 4), sort_ms=round(float(stage[1]), 4),
+                hierarchy_ms=round(float(stage[2] + stage[3] + stage[4]), 4),
                 hbm_frac=round(312.0 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 sort_hbm_frac=round(72.0 * n / (float(stage[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 

@@ -371,7 +371,7 @@ class Tracer:
     def build_stage_ms(self):
         out = np.zeros(5, dtype=np.float32)
         check(lib.cpt_tracer_build_stage_ms(self.h, out.ctypes.data))
-        return dict(zip(["morton", "sort", "gather", "karras", "refit"], out.tolist()))
+        return dict(zip(["morton", "sort", "hierarchy_workgroup", "hierarchy_memory", "reserved"], out.tolist()))
 
 
 def write_exr(path, rgba):

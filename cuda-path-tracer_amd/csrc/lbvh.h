@@ -24,7 +24,7 @@ struct BuildWorkspace {
 //               when given, bboxes[n-1..] need not be filled and one device copy is saved
 //   keys_out    optional device array of n sorted 64-bit keys (code << 32 | primitive)
 //   parents_out optional device array of 2n-1 parent indices (entry 0 is never written)
-//   stage_ms    optional host array of 5 floats: morton, sort, gather, karras, refit (forces a sync)
+//   stage_ms    optional host array of 5 floats: morton, sort, hierarchy pass one (leaf gather + everything inside a workgroup's leaves), hierarchy pass two (nodes spanning workgroups), 0 (forces a sync)
 // Returns 0 or a hipError_t value.
 int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t num_primitives, hipStream_t stream, BuildWorkspace *ws,
                const Bbox *leaf_src, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms);

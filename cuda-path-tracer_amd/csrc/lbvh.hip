@@ -1,13 +1,14 @@
-// Linear BVH builder for gfx950: 30-bit Morton keys, LDS-staged stable LSD radix sort,
-// Karras internal-node split, bottom-up refit with per-node arrival counters, and packing into
-// 64-byte traversal records.
+// Linear BVH builder for gfx950: 30-bit Morton keys, LDS-staged stable LSD radix sort, one
+// bottom-up pass for leaf order, topology and boxes (in LDS inside a workgroup's leaves, through
+// memory above them), and packing into 64-byte traversal records.
 //
 // Results are bit-identical to the reference builder (src/kernels/accel/accel_build.cu):
 //   keys      : accel_build.cu:25-41  (same IEEE expression, 0/0 on a flat axis -> 1023)
 //   order     : accel_build.cu:193    (ascending 64-bit keys; keys are unique because the low
 //               word is the primitive index, and the indices enter in ascending order, so a
 //               STABLE sort on the 30 code bits alone yields the same permutation)
-//   topology  : accel_build.cu:57-138 (Karras 2012 range/split searches on the 64-bit keys)
+//   topology  : accel_build.cu:57-138 (Karras 2012: the binary radix tree of the 64-bit keys with
+//               its node numbering, grown here from the leaves instead of searched from the top)
 //   boxes     : accel_build.cu:140-180 (min/max are exact and order independent; the sign-split
 //               integer atomics there order -0 below +0, reproduced here with a total order)
 #include "lbvh.h"
@@ -215,62 +216,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_leaves(const uint64_t *__rest
     nodes[(n - 1) + i] = AccelNode{prim, ~0u};
 }
 
-constexpr uint32_t kLocalBit = 0x80000000u;
-
 __device__ inline uint32_t lcp(uint64_t a, uint64_t b) {           // accel_build.cu:53-55
     uint64_t x = a ^ b;
     return x ? (uint32_t)__builtin_clzll(x) : 64u;
-}
-
-// Karras 2012 as written at accel_build.cu:57-138
-__global__ void __launch_bounds__(kBlock) k_karras(AccelNode *__restrict__ nodes, uint32_t *__restrict__ parents, const uint64_t *__restrict__ codes,
-                                                    uint32_t n) {
-    uint32_t index = blockIdx.x * kBlock + threadIdx.x;
-    if (index >= n - 1) return;
-    uint32_t first, last;
-    if (index == 0) {
-        first = 0;
-        last = n - 1;
-    } else {
-        uint64_t code = codes[index];
-        uint32_t l_lcp = lcp(code, codes[index - 1]);
-        uint32_t r_lcp = lcp(code, codes[index + 1]);
-        int d = l_lcp > r_lcp ? -1 : 1;
-        uint32_t min_lcp = min(l_lcp, r_lcp);
-        uint32_t step = 1;
-        uint32_t j_lcp;
-        do {
-            step <<= 1;
-            int j = (int)(index + (uint32_t)d * step);
-            j_lcp = 0;
-            if (j >= 0 && (uint32_t)j < n) j_lcp = lcp(code, codes[j]);
-        } while (j_lcp > min_lcp);
-        uint32_t l = step >> 1;
-        uint32_t r = min(step, d == -1 ? index : n - 1 - index);
-        while (l < r) {
-            uint32_t mid = l + ((r - l) >> 1) + 1;
-            uint32_t j = index + (uint32_t)d * mid;
-            if (lcp(code, codes[j]) < min_lcp) r = mid - 1; else l = mid;
-        }
-        r = index + (uint32_t)d * l;
-        l = index;
-        if (l <= r) { first = l; last = r; } else { first = r; last = l; }
-    }
-    uint64_t l_code = codes[first];
-    uint32_t node_lcp = lcp(l_code, codes[last]);
-    uint32_t l = first, r = last;
-    while (l < r) {
-        uint32_t mid = l + ((r - l) >> 1);
-        if (lcp(l_code, codes[mid]) > node_lcp) l = mid + 1; else r = mid;
-    }
-    uint32_t lc = l - 1, rc = l;
-    if (lc == first) lc += n - 1;
-    if (rc == last) rc += n - 1;
-    nodes[index] = AccelNode{lc, rc};
-    // bit 31 marks a parent whose whole leaf range lies inside one refit workgroup's 256 leaves
-    uint32_t tag = (first / kBlock == last / kBlock) ? (index | kLocalBit) : index;
-    parents[lc] = tag;
-    parents[rc] = tag;
 }
 
 // Total order on floats in which -0 sorts below +0: the order the reference's integer-atomic
@@ -305,124 +253,297 @@ __device__ inline void store_box_sc1(Bbox *p, f32x4 lo, f32x4 hi) {
                  : "memory");
 }
 
-// Bottom-up refit: one lane per leaf climbs towards the root; at every parent the first arrival
-// stops and the second merges both children.
+// ------------------------------------------------------------------------------------------
+// Hierarchy in one bottom-up pass: leaf gather + topology + boxes.
 //
-// Leaves are in sorted order and an internal node's index is one end of its leaf range, so a
-// node whose range lies inside the 256 leaves of one workgroup is only ever touched by that
-// workgroup and owns the LDS slot (index - first leaf of the workgroup).  Those nodes -- all but
-// a few per workgroup -- hand their boxes over through LDS with workgroup-scope atomics.  Only
-// nodes whose range crosses a workgroup boundary use memory: the child box is written with
-// device-scope write-through stores, drained, and then announced by a device-scope arrival
-// counter; the merging lane reads the sibling with device-scope loads that bypass the per-CU
-// cache.  No cache-wide fence is needed and the result does not depend on where lanes run.
-__global__ void __launch_bounds__(kBlock) k_refit(const uint32_t *__restrict__ parents, const AccelNode *__restrict__ nodes, Bbox *bboxes,
-                                                   uint32_t *arrivals, Bbox merged, uint32_t n) {
-    __shared__ float s_box[kBlock][6];          // boxes of finished internal nodes, slot = node index - block_first
-    __shared__ float s_leaf[kBlock][6];         // this workgroup's leaf boxes
-    __shared__ uint2 s_nodes[kBlock];           // children of internal nodes block_first .. block_first + 255
-    __shared__ uint32_t s_parent[kBlock];       // their parent tags
-    __shared__ uint32_t s_arrivals[kBlock];
-    const uint32_t block_first = blockIdx.x * kBlock;
-    const uint32_t i = block_first + threadIdx.x;
-    s_arrivals[threadIdx.x] = 0;
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (i < n) {
-        const float4 *lb = reinterpret_cast<const float4 *>(bboxes + (n - 1) + i);
-        float4 lo4 = lb[0], hi4 = lb[1];
-        lo[0] = lo4.x; lo[1] = lo4.y; lo[2] = lo4.z; hi[0] = hi4.x; hi[1] = hi4.y; hi[2] = hi4.z;
-        float *sl = s_leaf[threadIdx.x];
-        sl[0] = lo[0]; sl[1] = lo[1]; sl[2] = lo[2]; sl[3] = hi[0]; sl[4] = hi[1]; sl[5] = hi[2];
-    }
-    if (i < n - 1) {
-        AccelNode nd = nodes[i];
-        s_nodes[threadIdx.x] = make_uint2(nd.lc_or_id, nd.rc);
-        s_parent[threadIdx.x] = i > 0 ? parents[i] : 0u;
-    }
-    __syncthreads();
-    if (i >= n) return;
-    uint32_t cur = (n - 1) + i;
-    bool cur_internal = false;
-    // internal boxes start from the inverted merged box (accel_build.cu:140-148)
-    const float init_lo[3] = {merged.pmax.x, merged.pmax.y, merged.pmax.z};
-    const float init_hi[3] = {merged.pmin.x, merged.pmin.y, merged.pmin.z};
-    uint32_t tag = parents[cur];
-    for (;;) {
-        const uint32_t cslot = cur - block_first;
-        const uint32_t pa = tag & ~kLocalBit;
-        const bool local = (tag & kLocalBit) != 0;
-        // The parent's children and its own parent tag are read-only here (written by earlier
-        // kernels): fetch them now so that the loads overlap the hand-off below.
-        const uint32_t pslot = pa - block_first;
-        uint2 nd;
-        uint32_t next_tag = 0;
-        if (pslot < kBlock) {
-            nd = s_nodes[pslot];
-            next_tag = s_parent[pslot];
-        } else {
-            AccelNode g = nodes[pa];
-            nd = make_uint2(g.lc_or_id, g.rc);
-            if (pa != 0) next_tag = parents[pa];
-        }
-        uint32_t seen;
-        if (local) {
-            if (cur_internal) {
-                float *sb = s_box[cslot];
-                sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
-                float4 *gb = reinterpret_cast<float4 *>(bboxes + cur);
-                gb[0] = make_float4(lo[0], lo[1], lo[2], merged.pmax.w);
-                gb[1] = make_float4(hi[0], hi[1], hi[2], merged.pmin.w);
-            }
-            seen = __hip_atomic_fetch_add(&s_arrivals[pslot], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            if (cur_internal) {
-                f32x4 olo = {lo[0], lo[1], lo[2], merged.pmax.w}, ohi = {hi[0], hi[1], hi[2], merged.pmin.w};
-                store_box_sc1(bboxes + cur, olo, ohi);
-            }
-            seen = __hip_atomic_fetch_add(&arrivals[pa], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (seen == 0) return;
-        const uint32_t sib = nd.x == cur ? nd.y : nd.x;
-        float slo[3], shi[3];
-        if (sib >= n - 1) {                       // a leaf: written by an earlier kernel
-            const uint32_t lslot = sib - (n - 1) - block_first;
-            if (lslot < kBlock) {
-                const float *sl = s_leaf[lslot];
-                slo[0] = sl[0]; slo[1] = sl[1]; slo[2] = sl[2]; shi[0] = sl[3]; shi[1] = sl[4]; shi[2] = sl[5];
-            } else {
-                const float4 *sp = reinterpret_cast<const float4 *>(bboxes + sib);
-                float4 a4 = sp[0], b4 = sp[1];
-                slo[0] = a4.x; slo[1] = a4.y; slo[2] = a4.z; shi[0] = b4.x; shi[1] = b4.y; shi[2] = b4.z;
-            }
-        } else if (local) {
-            const float *sb = s_box[sib - block_first];
-            slo[0] = sb[0]; slo[1] = sb[1]; slo[2] = sb[2]; shi[0] = sb[3]; shi[1] = sb[4]; shi[2] = sb[5];
-        } else {
-            f32x4 a4, b4;
-            load_box_sc1(bboxes + sib, a4, b4);
-            slo[0] = a4[0]; slo[1] = a4[1]; slo[2] = a4[2]; shi[0] = b4[0]; shi[1] = b4[1]; shi[2] = b4[2];
-        }
+// The tree the reference builds top-down (accel_build.cu:57-138) is the binary radix tree of the
+// sorted keys, which is unique because the keys are; only the numbering is Karras': the left child
+// of a split between sorted positions g and g+1 is node g (leaf n-1+g when its range is the single
+// key g), the right child is node g+1 (leaf n-1+g+1), the root is node 0.  The same tree grows from
+// the leaves (Apetrei 2014): a node covering sorted keys [l, r] is merged first with the neighbour
+// it shares the longer prefix with, d(j) = lcp(key j, key j+1): if d(r) > d(l-1) it is the LEFT
+// child of the split g = r, otherwise the RIGHT child of the split g = l-1 (d(-1) = d(n-1) = -1;
+// d(r) = d(l-1) cannot happen with distinct keys).  That fixes the node's own number (r or l), so
+// it can write its record and box, and hand over to the sibling through one exchange word per
+// split: the first child to arrive leaves the far end of its range there and stops, the second
+// one picks it up -- it then knows the parent's range, both child numbers, and where the
+// sibling's box is -- merges, and goes on as the parent.  No binary searches, no separate parents
+// array, one kernel instead of gather + topology + refit.
+//
+// A split whose parent covers only leaves of one workgroup is exchanged through LDS.  Both
+// children must take the same decision knowing only their own half of the parent's range, so
+// the workgroup precomputes it per split from the 257 prefix lengths it can see: the parent of
+// split g stays inside the workgroup's leaves [b0, b1] iff some d(j) < d(g) with b0-1 <= j < g and
+// some d(j) < d(g) with g < j <= b1 (two running minima).  All other splits use memory:
+// device-scope write-through stores of the child box, a device-scope exchange, and device-scope
+// loads of the sibling box.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSlotValid = 0x80000000u;
+constexpr int kUpBlock = 512;              // leaves per workgroup of the bottom-up pass
+
+__device__ inline int wave_incl_min(int v) {
+    int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = tmin(init_lo[a], tmin(lo[a], slo[a]));
-            hi[a] = tmax(init_hi[a], tmax(hi[a], shi[a]));
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v = min(v, t);
+    }
+    return v;
+}
+__device__ inline int wave_incl_min_rev(int v) {       // suffix minimum
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_down(v, d, 64);
+        if (lane + d < 64) v = min(v, t);
+    }
+    return v;
+}
+
+// Boxes travel through the pass as order keys (order_key(): unsigned integers whose order is the
+// total order above), so a merge is six integer min/max operations; they are turned back into
+// floats, and folded with the inverted merged box every internal box starts from
+// (accel_build.cu:140-148), only where a box is written.
+__device__ inline float key_to_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// A node that still has to meet its sibling, handed from the workgroup pass to the memory pass.
+struct Carrier { uint32_t l, r, idx, pad; };
+constexpr uint32_t kCarriersPerGroup = 64;       // per workgroup of the first pass; the (rare) rest climbs in place
+
+// The climb through splits whose parent spans several workgroups: exchange words and boxes in
+// memory.  On entry node `idx` covers sorted keys [l, r], its record is written and its box is in
+// lo/hi; `in_memory` tells whether the box is already visible in bboxes[idx] to every CU (written
+// by an earlier kernel), otherwise it is stored write-through (w components lw, hw) first.
+template <bool PARENTS>
+__device__ inline void climb_global(uint32_t l, uint32_t r, uint32_t idx, uint32_t lo[3], uint32_t hi[3], bool in_memory, float lw, float hw,
+                                    const uint64_t *__restrict__ keys, Bbox *bboxes, AccelNode *nodes, uint32_t *parents, uint32_t *slots,
+                                    const Bbox &merged, uint32_t n) {
+    const uint32_t init_lo[3] = {order_key(merged.pmax.x), order_key(merged.pmax.y), order_key(merged.pmax.z)};
+    const uint32_t init_hi[3] = {order_key(merged.pmin.x), order_key(merged.pmin.y), order_key(merged.pmin.z)};
+    auto delta_before = [&](uint32_t j1) -> int {          // prefix shared by sorted keys j1-1 and j1
+        if (j1 == 0 || j1 >= n) return -1;
+        return (int)lcp(keys[j1 - 1], keys[j1]);
+    };
+    uint32_t lc = 0, rc = 0;
+    bool have_record = true;
+    for (;;) {
+        const bool left_child = delta_before(r + 1) > delta_before(l);
+        const uint32_t g = left_child ? r : l - 1;
+        if (!have_record) {
+            idx = left_child ? r : l;
+            nodes[idx] = AccelNode{lc, rc};
+            if (PARENTS) { parents[lc] = idx; parents[rc] = idx; }
         }
-        cur = pa;
-        cur_internal = true;
-        tag = next_tag;
-        if (cur == 0) {
+        if (!in_memory) {
+            f32x4 olo, ohi;
+            if (have_record) {          // the entry node as it is (a leaf keeps its own box and w)
+                olo = f32x4{key_to_float(lo[0]), key_to_float(lo[1]), key_to_float(lo[2]), lw};
+                ohi = f32x4{key_to_float(hi[0]), key_to_float(hi[1]), key_to_float(hi[2]), hw};
+            } else {
+                olo = f32x4{key_to_float(min(init_lo[0], lo[0])), key_to_float(min(init_lo[1], lo[1])), key_to_float(min(init_lo[2], lo[2])), merged.pmax.w};
+                ohi = f32x4{key_to_float(max(init_hi[0], hi[0])), key_to_float(max(init_hi[1], hi[1])), key_to_float(max(init_hi[2], hi[2])), merged.pmin.w};
+            }
+            store_box_sc1(bboxes + idx, olo, ohi);
+        }
+        const uint32_t far = (left_child ? l : r) | kSlotValid;
+        const uint32_t prev = __hip_atomic_exchange(&slots[g], far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) return;
+        const uint32_t sib_far = prev & ~kSlotValid;
+        uint32_t sib;
+        if (left_child) {                                  // sibling = right child, keys [g+1, sib_far]
+            sib = sib_far == g + 1 ? (n - 1) + g + 1 : g + 1;
+            lc = idx; rc = sib; r = sib_far;
+        } else {                                           // sibling = left child, keys [sib_far, g]
+            sib = sib_far == g ? (n - 1) + g : g;
+            lc = sib; rc = idx; l = sib_far;
+        }
+        f32x4 a4, b4;
+        load_box_sc1(bboxes + sib, a4, b4);
+        lo[0] = min(lo[0], order_key(a4[0])); lo[1] = min(lo[1], order_key(a4[1])); lo[2] = min(lo[2], order_key(a4[2]));
+        hi[0] = max(hi[0], order_key(b4[0])); hi[1] = max(hi[1], order_key(b4[1])); hi[2] = max(hi[2], order_key(b4[2]));
+        have_record = false;
+        in_memory = false;
+        if (l == 0 && r == n - 1) {                       // the root is node 0
+            nodes[0] = AccelNode{lc, rc};
+            if (PARENTS) { parents[lc] = 0; parents[rc] = 0; }
             float4 *gb = reinterpret_cast<float4 *>(bboxes);
-            gb[0] = make_float4(lo[0], lo[1], lo[2], merged.pmax.w);
-            gb[1] = make_float4(hi[0], hi[1], hi[2], merged.pmin.w);
+            gb[0] = make_float4(key_to_float(min(init_lo[0], lo[0])), key_to_float(min(init_lo[1], lo[1])), key_to_float(min(init_lo[2], lo[2])), merged.pmax.w);
+            gb[1] = make_float4(key_to_float(max(init_hi[0], hi[0])), key_to_float(max(init_hi[1], hi[1])), key_to_float(max(init_hi[2], hi[2])), merged.pmin.w);
             return;
         }
     }
 }
 
-// parent links without the locality tag, for callers that ask for the reference's parents array
-__global__ void __launch_bounds__(kBlock) k_strip_parents(uint32_t *__restrict__ out, const uint32_t *__restrict__ parents, uint32_t count) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= 1 && i < count) out[i] = parents[i] & ~kLocalBit;
+// second pass: one lane per carrier of the first pass
+template <bool PARENTS>
+__global__ void __launch_bounds__(kBlock) k_climb(const Carrier *__restrict__ carriers, const uint32_t *__restrict__ counts, uint32_t groups,
+                                                   const uint64_t *__restrict__ keys, Bbox *bboxes, AccelNode *nodes, uint32_t *parents, uint32_t *slots,
+                                                   Bbox merged, uint32_t n) {
+    const uint32_t group = blockIdx.x * (kBlock / kCarriersPerGroup) + threadIdx.x / kCarriersPerGroup, k = threadIdx.x % kCarriersPerGroup;
+    if (group >= groups || k >= counts[group]) return;
+    const Carrier c = carriers[(size_t)group * kCarriersPerGroup + k];
+    const float4 *b = reinterpret_cast<const float4 *>(bboxes + c.idx);       // stored by the first pass
+    const float4 a4 = b[0], b4 = b[1];
+    uint32_t lo[3] = {order_key(a4.x), order_key(a4.y), order_key(a4.z)}, hi[3] = {order_key(b4.x), order_key(b4.y), order_key(b4.z)};
+    climb_global<PARENTS>(c.l, c.r, c.idx, lo, hi, true, a4.w, b4.w, keys, bboxes, nodes, parents, slots, merged, n);
+}
+
+template <bool PARENTS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__ keys, const Bbox *__restrict__ leaf_src, Bbox *bboxes, AccelNode *nodes,
+                                                    uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, Bbox merged, uint32_t n) {
+    __shared__ Carrier s_park[kCarriersPerGroup];
+    __shared__ uint32_t s_park_count;
+    __shared__ uint64_t s_key[BLOCK + 2];        // keys b0-1 .. b1+1
+    __shared__ int s_delta[BLOCK + 1];           // d(b0-1) .. d(b1)
+    __shared__ int s_wave_min[2][BLOCK / 64];
+    __shared__ int s_lmin[BLOCK], s_rmin[BLOCK + 2];
+    __shared__ uint8_t s_local[BLOCK];           // split b0+t: the parent stays inside this workgroup
+    __shared__ uint32_t s_slot[BLOCK];           // exchange words of those splits
+    __shared__ uint32_t s_box[BLOCK][6];         // boxes (order keys) of internal nodes b0 .. b1
+    __shared__ uint32_t s_leaf[BLOCK][6];        // boxes (order keys) of this workgroup's leaves
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t b0 = blockIdx.x * BLOCK;
+    const uint32_t i = b0 + t;
+
+    // ---- keys, leaf gather (accel_build.cu:43-51 and the payload permutation of :193)
+    uint64_t key = 0;
+    uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (i < n) {
+        key = keys[i];
+        const uint32_t prim = (uint32_t)key;
+        const float4 *src = reinterpret_cast<const float4 *>(leaf_src + prim);
+        const float4 a = src[0], b = src[1];
+        float4 *dst = reinterpret_cast<float4 *>(bboxes + (n - 1) + i);
+        dst[0] = a;
+        dst[1] = b;
+        nodes[(n - 1) + i] = AccelNode{prim, ~0u};
+        lo[0] = order_key(a.x); lo[1] = order_key(a.y); lo[2] = order_key(a.z);
+        hi[0] = order_key(b.x); hi[1] = order_key(b.y); hi[2] = order_key(b.z);
+        uint32_t *sl = s_leaf[t];
+        sl[0] = lo[0]; sl[1] = lo[1]; sl[2] = lo[2]; sl[3] = hi[0]; sl[4] = hi[1]; sl[5] = hi[2];
+    }
+    s_key[t + 1] = key;
+    if (t == 0) s_key[0] = b0 > 0 ? keys[b0 - 1] : 0ull;
+    if (t == 1) s_key[BLOCK + 1] = (b0 + BLOCK < n) ? keys[b0 + BLOCK] : 0ull;
+    s_slot[t] = 0;
+    if (t == 0) s_park_count = 0;
+    __syncthreads();
+    // d(j) for j = b0-1+k, k = 0 .. BLOCK: -1 outside the key array
+    auto delta_of_window = [&](uint32_t k) -> int {
+        const uint32_t j1 = b0 + k;                         // j + 1
+        if (j1 == 0 || j1 >= n) return -1;
+        return (int)lcp(s_key[k], s_key[k + 1]);
+    };
+    const int d_here = delta_of_window(t);
+    s_delta[t] = d_here;
+    if (t == 0) s_delta[BLOCK] = delta_of_window(BLOCK);
+    // running minima: s_lmin[k] = min d(window 0..k), s_rmin[k] = min d(window k..BLOCK)
+    int lmin = wave_incl_min(d_here), rmin = wave_incl_min_rev(d_here);
+    if (lane == 63) s_wave_min[0][w] = lmin;
+    if (lane == 0) s_wave_min[1][w] = rmin;
+    __syncthreads();
+    for (uint32_t k = 0; k < (uint32_t)(BLOCK / 64); k++) {
+        if (k < w) lmin = min(lmin, s_wave_min[0][k]);
+        if (k > w) rmin = min(rmin, s_wave_min[1][k]);
+    }
+    s_lmin[t] = lmin;
+    s_rmin[t] = min(rmin, s_delta[BLOCK]);
+    if (t == 0) { s_rmin[BLOCK] = s_delta[BLOCK]; s_rmin[BLOCK + 1] = 0x7fffffff; }
+    __syncthreads();
+    {
+        // split g = b0 + t has d(g) = window entry t+1; left candidates are entries 0..t, right ones t+2..BLOCK
+        const int dg = s_delta[t + 1];
+        s_local[t] = (dg >= 0 && s_lmin[t] < dg && s_rmin[t + 2] < dg) ? 1 : 0;
+    }
+    __syncthreads();
+
+    // d(j1 - 1): prefix shared by sorted keys j1-1 and j1
+    auto delta_before = [&](uint32_t j1) -> int {
+        if (j1 == 0 || j1 >= n) return -1;
+        const uint32_t k = j1 - b0;                         // window entry of j = j1 - 1
+        if (k <= (uint32_t)BLOCK) return s_delta[k];
+        return (int)lcp(keys[j1 - 1], keys[j1]);
+    };
+    const uint32_t init_lo[3] = {order_key(merged.pmax.x), order_key(merged.pmax.y), order_key(merged.pmax.z)};
+    const uint32_t init_hi[3] = {order_key(merged.pmin.x), order_key(merged.pmin.y), order_key(merged.pmin.z)};
+    auto box_lo = [&]() { return make_float4(key_to_float(min(init_lo[0], lo[0])), key_to_float(min(init_lo[1], lo[1])), key_to_float(min(init_lo[2], lo[2])), merged.pmax.w); };
+    auto box_hi = [&]() { return make_float4(key_to_float(max(init_hi[0], hi[0])), key_to_float(max(init_hi[1], hi[1])), key_to_float(max(init_hi[2], hi[2])), merged.pmin.w); };
+    uint32_t l = i, r = i, lc = 0, rc = 0;
+    bool internal = false;
+    while (i < n) {
+        if (l == 0 && r == n - 1) {                       // the root is node 0
+            nodes[0] = AccelNode{lc, rc};
+            if (PARENTS) { parents[lc] = 0; parents[rc] = 0; }
+            float4 *gb = reinterpret_cast<float4 *>(bboxes);
+            gb[0] = box_lo();
+            gb[1] = box_hi();
+            break;
+        }
+        const bool left_child = delta_before(r + 1) > delta_before(l);
+        const uint32_t g = left_child ? r : l - 1;
+        const uint32_t idx = internal ? (left_child ? r : l) : (n - 1) + i;
+        const uint32_t gs = g - b0;
+        if (internal) {
+            nodes[idx] = AccelNode{lc, rc};
+            if (PARENTS) { parents[lc] = idx; parents[rc] = idx; }
+            float4 *gb = reinterpret_cast<float4 *>(bboxes + idx);
+            gb[0] = box_lo();
+            gb[1] = box_hi();
+        }
+        if (!(gs < (uint32_t)BLOCK && s_local[gs] != 0)) {
+            // The parent spans several workgroups.  The node is complete (record and box stored);
+            // it meets its sibling in the second pass, which starts after this kernel has ended,
+            // so that the memory round trips of that exchange do not stall the lanes of this wave
+            // that still work in LDS.
+            const uint32_t slot = atomicAdd(&s_park_count, 1u);
+            if (slot < kCarriersPerGroup) {
+                s_park[slot] = Carrier{l, r, idx, 0u};
+            } else {                                      // no room: climb from here, through memory
+                float lw = merged.pmax.w, hw = merged.pmin.w;
+                if (!internal) {
+                    const float4 *own = reinterpret_cast<const float4 *>(leaf_src + (uint32_t)key);
+                    lw = own[0].w; hw = own[1].w;
+                } else {                                  // the stored box is the folded one
+                    for (int a = 0; a < 3; a++) { lo[a] = min(init_lo[a], lo[a]); hi[a] = max(init_hi[a], hi[a]); }
+                }
+                climb_global<PARENTS>(l, r, idx, lo, hi, false, lw, hw, keys, bboxes, nodes, parents, slots, merged, n);
+            }
+            break;
+        }
+        if (internal) {
+            uint32_t *sb = s_box[idx - b0];
+            sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
+        }
+        // LDS executes a wave's operations in issue order, so the box written above is in place
+        // when another wave sees the exchange and reads it afterwards; only the compiler has to
+        // be kept from moving the accesses.  (An acquire/release exchange would also wait for
+        // the global stores above, a round trip to memory per level of the climb.)
+        const uint32_t far = (left_child ? l : r) | kSlotValid;
+        asm volatile("" ::: "memory");
+        const uint32_t prev = __hip_atomic_exchange(&s_slot[gs], far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (prev == 0) break;
+        const uint32_t sib_far = prev & ~kSlotValid;
+        uint32_t sib;
+        if (left_child) {                                  // sibling = right child, keys [g+1, sib_far]
+            sib = sib_far == g + 1 ? (n - 1) + g + 1 : g + 1;
+            lc = idx; rc = sib; r = sib_far;
+        } else {                                           // sibling = left child, keys [sib_far, g]
+            sib = sib_far == g ? (n - 1) + g : g;
+            lc = sib; rc = idx; l = sib_far;
+        }
+        const uint32_t *sb = sib >= n - 1 ? s_leaf[sib - (n - 1) - b0] : s_box[sib - b0];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = min(lo[a], sb[a]);
+            hi[a] = max(hi[a], sb[3 + a]);
+        }
+        internal = true;
+    }
+    __syncthreads();
+    const uint32_t parked = min(s_park_count, kCarriersPerGroup);
+    if (t < parked) carriers[(size_t)blockIdx.x * kCarriersPerGroup + t] = s_park[t];
+    if (t == 0) carrier_counts[blockIdx.x] = parked;
 }
 
 // ---- packing into traversal records --------------------------------------------------------
@@ -503,8 +624,9 @@ size_t BuildWorkspace::bytes_for(uint32_t n) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return up(8 * (size_t)n) * 2               // keys ping/pong
          + up(32 * (size_t)n)                  // unsorted leaf boxes
-         + up(4 * (2 * (size_t)n))             // parents
-         + up(4 * (size_t)n)                   // arrival counters
+         + up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock))   // carriers between the two hierarchy passes
+         + up(4 * (size_t)cdiv(n, kUpBlock))   // their counts
+         + up(4 * (size_t)n)                   // one exchange word per split
          + up(4 * tiles * kBins)               // tile histograms (bin-major)
          + up(4 * kBins);                      // bin totals
 }
@@ -537,8 +659,9 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     uint64_t *keys_a = reinterpret_cast<uint64_t *>(p); p += up(8 * (size_t)n);
     uint64_t *keys_b = reinterpret_cast<uint64_t *>(p); p += up(8 * (size_t)n);
     Bbox *leaf_tmp = reinterpret_cast<Bbox *>(p); p += up(32 * (size_t)n);
-    uint32_t *parents = reinterpret_cast<uint32_t *>(p); p += up(4 * (2 * (size_t)n));
-    uint32_t *arrivals = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)n);
+    Carrier *carriers = reinterpret_cast<Carrier *>(p); p += up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock));
+    uint32_t *carrier_counts = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)cdiv(n, kUpBlock));
+    uint32_t *slots = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)n);
     uint32_t *tile_hist = reinterpret_cast<uint32_t *>(p); p += up(4 * tiles * kBins);
     uint32_t *bin_total = reinterpret_cast<uint32_t *>(p);
 
@@ -569,19 +692,29 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
         }
     }
     mark(2);
-    hipLaunchKernelGGL(k_gather_leaves, dim3(grid_n), dim3(kBlock), 0, stream, src, leaf_src, bboxes, nodes, n);
-    mark(3);
     if (n > 1) {
-        HIP_OK(hipMemsetAsync(arrivals, 0, 4 * (size_t)(n - 1), stream));
-        hipLaunchKernelGGL(k_karras, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, nodes, parents, src, n);
-        mark(4);
-        hipLaunchKernelGGL(k_refit, dim3(grid_n), dim3(kBlock), 0, stream, parents, nodes, bboxes, arrivals, merged, n);
+        const uint32_t groups = cdiv(n, kUpBlock);
+        HIP_OK(hipMemsetAsync(slots, 0, 4 * (size_t)(n - 1), stream));      // one exchange word per split
+        if (parents_out) {
+            hipLaunchKernelGGL((k_build_up<true, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers,
+                               carrier_counts, merged, n);
+            mark(3);
+            hipLaunchKernelGGL(k_climb<true>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
+                               bboxes, nodes, parents_out, slots, merged, n);
+        } else {
+            hipLaunchKernelGGL((k_build_up<false, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, (uint32_t *)nullptr, slots,
+                               carriers, carrier_counts, merged, n);
+            mark(3);
+            hipLaunchKernelGGL(k_climb<false>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
+                               bboxes, nodes, (uint32_t *)nullptr, slots, merged, n);
+        }
     } else {
-        mark(4);
+        hipLaunchKernelGGL(k_gather_leaves, dim3(grid_n), dim3(kBlock), 0, stream, src, leaf_src, bboxes, nodes, n);
+        mark(3);
     }
+    mark(4);
     mark(5);
     if (keys_out) HIP_OK(hipMemcpyAsync(keys_out, src, 8 * (size_t)n, hipMemcpyDeviceToDevice, stream));
-    if (parents_out && n > 1) hipLaunchKernelGGL(k_strip_parents, dim3(cdiv(2 * n - 1, kBlock)), dim3(kBlock), 0, stream, parents_out, parents, 2 * n - 1);
     HIP_OK(hipGetLastError());
     if (stage_ms) {
         HIP_OK(hipStreamSynchronize(stream));

@@ -56,7 +56,8 @@ int cpt_build_accel(void *d_nodes, void *d_bboxes, const float merged_bbox[8], u
 /* Same build with the intermediate arrays exposed for parity checks and profiling (all optional):
  *   d_keys_out    n sorted 64-bit keys, (morton30 << 32) | primitive index
  *   d_parents_out 2n-1 parent indices (entry 0 is never written, as in the reference)
- *   stage_ms      host array of 5: morton, sort, gather, karras, refit milliseconds */
+ *   stage_ms      host array of 5 milliseconds: morton, sort, hierarchy pass one (leaf gather, topology and boxes
+ *                 inside each workgroup's leaves), hierarchy pass two (nodes spanning workgroups), 0 */
 int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives, uint64_t *d_keys_out,
                        uint32_t *d_parents_out, float *stage_ms);
 
