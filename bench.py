@@ -45,7 +45,7 @@ def algorithmic_bytes(c, pixels_per_launch, launches):
     return total / max(launches, 1)
 
 
-def lbvh_timings(cpt, n, seed=12345, repeats=10):
+def lbvh_timings(cpt, n, seed=12345, repeats=10, sort_variant=0):
     """Median device time of the whole build (Morton -> sort -> nodes -> refit) with buffers
     pre-allocated, after two warm-ups; plus the per-stage split of one extra run (hierarchy = leaf
     gather + topology + boxes, two kernels)."""
@@ -57,6 +57,7 @@ def lbvh_timings(cpt, n, seed=12345, repeats=10):
     d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
     d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
     b = cpt.lib.cpt_builder_create()
+    cpt.check(cpt.lib.cpt_builder_set_sort(b, sort_variant))
     times = []
     for i in range(repeats + 2):
         ms = C.c_float(0.0)

@@ -127,6 +127,12 @@ void cpt_builder_destroy(cpt_builder *b) {
     delete b;
 }
 
+int cpt_builder_set_sort(cpt_builder *b, int variant) {
+    if (!b || variant < 0 || variant > 1) return Fail(CPT_ERR_INVALID, "cpt_builder_set_sort: variant must be 0 or 1");
+    b->ws.sort_variant = variant;
+    return CPT_OK;
+}
+
 int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
                       uint32_t num_primitives, float *elapsed_ms, float *stage_ms) {
     if (!b || !d_nodes || !d_bboxes || !merged_bbox) return Fail(CPT_ERR_INVALID, "cpt_builder_build: null argument");

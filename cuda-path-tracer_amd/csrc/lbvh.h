@@ -10,6 +10,9 @@ namespace cpt {
 struct BuildWorkspace {
     void *base = nullptr;
     size_t capacity = 0;
+    // radix sort variant: 0 = tile histograms + scan + scatter per pass (default, faster on this part),
+    // 1 = onesweep (histograms with the keys, one look-back kernel per pass)
+    int sort_variant = 0;
     static size_t bytes_for(uint32_t num_primitives);
     int reserve(uint32_t num_primitives);
     void release();

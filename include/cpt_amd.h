@@ -67,6 +67,10 @@ int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8]
 typedef struct cpt_builder cpt_builder;
 cpt_builder *cpt_builder_create(void);
 void cpt_builder_destroy(cpt_builder *b);
+/* Radix sort used by this builder: 0 = per pass a tile histogram, a scan and a scatter kernel (default);
+ * 1 = onesweep: digit histograms computed with the keys, one kernel per pass with decoupled look-back.
+ * Same result; on MI355X variant 0 is the faster one (look-back steps cross the per-XCD L2s). */
+int cpt_builder_set_sort(cpt_builder *b, int variant);
 int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
                       uint32_t num_primitives, float *elapsed_ms, float *stage_ms);
 

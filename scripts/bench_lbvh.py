@@ -9,3 +9,4 @@ from conftest import load_cpt
 cpt = load_cpt()
 for n in [int(a) for a in sys.argv[1:]] or [1_000_000, 10_000_000]:
     print(n, bench.lbvh_timings(cpt, n), flush=True)
+    print(n, "onesweep", bench.lbvh_timings(cpt, n, sort_variant=1), flush=True)

@@ -129,6 +129,26 @@ def test_full_size_builds(cpt, n, kind):
     assert np.array_equal(g_boxes.view(np.uint32), o_boxes.view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [1, 2, 4097, 300000, 3_000_000])
+def test_onesweep_sort_variant_gives_the_same_tree(cpt, n):
+    """The one-kernel-per-pass sort (digit histograms with the keys, decoupled look-back) against the
+    oracle: same nodes and boxes as the default sort, bit for bit."""
+    soup = random_soup(n, seed=5 + n)
+    boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+    d_leaf = cpt.DeviceArray.from_host(boxes)
+    d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
+    d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
+    b = cpt.lib.cpt_builder_create()
+    cpt.check(cpt.lib.cpt_builder_set_sort(b, 1))
+    ms = np.zeros(1, np.float32)
+    for _ in range(2):
+        cpt.check(cpt.lib.cpt_builder_build(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, ms.ctypes.data, None))
+    cpt.lib.cpt_builder_destroy(b)
+    o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
+    assert np.array_equal(d_nodes.to_host(), o_nodes)
+    assert np.array_equal(d_boxes.to_host().view(np.uint32), o_boxes.view(np.uint32))
+
+
 def test_reusable_builder_is_deterministic(cpt):
     soup = random_soup(200000, seed=77)
     boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
