@@ -20,7 +20,9 @@ namespace cpt {
 namespace {
 
 constexpr int kBlock = 256;                 // 4 waves of 64
-constexpr int kItems = 16;                  // keys per thread in the sort kernels
+constexpr int kItems = 16;                  // keys per thread in the sort kernels (8 for small inputs: more, shorter workgroups)
+constexpr int kSmallItems = 8;
+constexpr uint32_t kSmallSort = 3000000;    // inputs up to this size sort with the small tile
 constexpr int kTile = kBlock * kItems;      // 4096 keys = 32 KB of LDS staging per workgroup
 constexpr int kWaves = kBlock / 64;
 constexpr int kRadixBits = 8;
@@ -259,14 +261,15 @@ __global__ void __launch_bounds__(kBlock) k_onesweep(const uint64_t *__restrict_
 // for another one; on this part that is faster than the look-back of the one-kernel pass above,
 // whose every step is a round trip past the per-XCD L2s (10M keys: 0.35 ms against 0.36-0.49 ms).
 // ------------------------------------------------------------------------------------------
+template <int ITEMS>
 __global__ void __launch_bounds__(kBlock) k_hist(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t *__restrict__ tile_hist,
                                                   uint32_t num_tiles) {
     __shared__ uint32_t hist[kBins];
     hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * kTile;
+    uint32_t base = blockIdx.x * (kBlock * ITEMS);
 #pragma unroll
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t i = base + k * kBlock + threadIdx.x;
         if (i < n) {
             uint32_t d = (uint32_t)(keys[i] >> shift) & (kBins - 1);
@@ -294,30 +297,34 @@ __global__ void __launch_bounds__(kBlock) k_scan_bins(uint32_t *__restrict__ til
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-__global__ void __launch_bounds__(kBlock) k_scatter(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t n, int shift,
+template <int ITEMS>
+__global__ void __launch_bounds__(kBlock, 4) k_scatter(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t n, int shift,
                                                      const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ bin_total,
                                                      uint32_t num_tiles) {
-    __shared__ uint64_t staged[kTile];           // keys in tile-sorted order
+    __shared__ uint64_t staged[(kBlock * ITEMS)];           // keys in tile-sorted order
     __shared__ uint32_t cnt[kWaves][kBins];      // per-wave digit counts, then exclusive over waves
     __shared__ uint32_t tile_off[kBins];         // first staged slot of each digit
     __shared__ uint32_t gbase[kBins];            // global destination of staged slot 0 of each digit
     __shared__ uint32_t tmp[kWaves + 1];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t tile_base = blockIdx.x * kTile;
-    const uint32_t tile_n = min((uint32_t)kTile, n - tile_base);
+    const uint32_t tile_base = blockIdx.x * (kBlock * ITEMS);
+    const uint32_t tile_n = min((uint32_t)(kBlock * ITEMS), n - tile_base);
+    // digit t's totals are not needed before the scatter: fetch them while the ranking runs
+    const uint32_t bt = bin_total[t];
+    const uint32_t earlier_tiles = tile_hist[(size_t)t * num_tiles + blockIdx.x];
 #pragma unroll
     for (int i = 0; i < kWaves; i++) cnt[i][t] = 0;
     __syncthreads();
 
     // Each wave owns a contiguous quarter of the tile and walks it 64 keys at a time, so key
     // order within the tile is (wave, round, lane): ranking in that order keeps the sort stable.
-    uint64_t key[kItems];
-    uint32_t rank[kItems];
+    uint64_t key[ITEMS];
+    uint32_t rank[ITEMS];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        uint32_t li = w * (64 * kItems) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; r++) {
+        uint32_t li = w * (64 * ITEMS) + r * 64 + lane;
         bool valid = li < tile_n;
         uint64_t k = valid ? keys_in[tile_base + li] : ~0ull;
         key[r] = k;
@@ -348,14 +355,13 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const uint64_t *__restrict__
     uint32_t off = block_excl_scan(total_d, tmp, all);
     tile_off[t] = off;
     __syncthreads();
-    uint32_t bt = bin_total[t];
     uint32_t bin_base = block_excl_scan(bt, tmp, all);
-    gbase[t] = bin_base + tile_hist[(size_t)t * num_tiles + blockIdx.x] - off;
+    gbase[t] = bin_base + earlier_tiles - off;
     __syncthreads();
 
 #pragma unroll
-    for (int r = 0; r < kItems; r++) {
-        uint32_t li = w * (64 * kItems) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; r++) {
+        uint32_t li = w * (64 * ITEMS) + r * 64 + lane;
         if (li < tile_n) {
             uint32_t d = (uint32_t)(key[r] >> shift) & (kBins - 1);
             staged[tile_off[d] + cnt[w][d] + rank[r]] = key[r];
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter(const uint64_t *__restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         uint32_t i = k * kBlock + t;
         if (i < tile_n) {
             uint64_t kk = staged[i];
@@ -791,7 +797,7 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 size_t BuildWorkspace::bytes_for(uint32_t n) {
     if (n == 0) return 0;
-    size_t tiles = cdiv(n, kTile);
+    size_t tiles = cdiv(n, kBlock * kSmallItems);      // the smaller tile of the two sort configurations
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return up(8 * (size_t)n) * 2               // keys ping/pong
          + up(32 * (size_t)n)                  // unsorted leaf boxes
@@ -870,11 +876,15 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
         mark(1);
         if (n > 1) {
             uint32_t *tile_hist = tile_status, *bin_total = digit_hist;     // same scratch, other use
+            const bool small = n <= kSmallSort;
+            const uint32_t nt = small ? cdiv(n, kBlock * kSmallItems) : (uint32_t)tiles;
             for (int pass = 0; pass < kPasses; pass++) {
                 int shift = 32 + pass * kRadixBits;
-                hipLaunchKernelGGL(k_hist, dim3((uint32_t)tiles), dim3(kBlock), 0, stream, src, n, shift, tile_hist, (uint32_t)tiles);
-                hipLaunchKernelGGL(k_scan_bins, dim3(kBins), dim3(kBlock), 0, stream, tile_hist, (uint32_t)tiles, bin_total);
-                hipLaunchKernelGGL(k_scatter, dim3((uint32_t)tiles), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, (uint32_t)tiles);
+                if (small) hipLaunchKernelGGL(k_hist<kSmallItems>, dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
+                else hipLaunchKernelGGL(k_hist<kItems>, dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
+                hipLaunchKernelGGL(k_scan_bins, dim3(kBins), dim3(kBlock), 0, stream, tile_hist, nt, bin_total);
+                if (small) hipLaunchKernelGGL(k_scatter<kSmallItems>, dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
+                else hipLaunchKernelGGL(k_scatter<kItems>, dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
                 uint64_t *t = src; src = dst; dst = t;
             }
         }
