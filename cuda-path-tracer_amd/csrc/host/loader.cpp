@@ -4,6 +4,8 @@
 #include "loader.hpp"
 
 #include <cctype>
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +14,7 @@
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 using cpt::V2;
@@ -32,14 +35,94 @@ bool ReadFile(const std::filesystem::path &path, std::string &out) {
 
 inline void SkipSpace(const char *&p) { while (*p == ' ' || *p == '\t' || *p == '\r') ++p; }
 inline bool AtEol(const char *p) { return *p == '\0' || *p == '\n'; }
+// A real number the way the reference's OBJ reader takes it (tinyobjloader's parseReal /
+// tryParseDouble, thirdparty/tinyobjloader/tiny_obj_loader.h:866-1006): the token runs to the next
+// blank; sign, digits, fraction and decimal exponent are accumulated in double (digit by digit,
+// fraction digits scaled by a table of powers of ten up to 1e-7 and pow(10, -k) beyond, exponent
+// applied as ldexp(m * 5^e, e)) and the result is narrowed to float.  Anything the grammar does
+// not accept ("nan", "inf", hex floats, an empty exponent) leaves the fallback value.  No
+// locale, no errno, and about ten times faster than strtof on files with millions of numbers.
+inline bool IsDigit(char c) { return (unsigned)(c - '0') < 10u; }
+inline bool ParseRealToken(const char *s, const char *s_end, double &result) {
+    if (s >= s_end) return false;
+    double mantissa = 0.0;
+    int exponent = 0;
+    char sign = '+', exp_sign = '+';
+    const char *curr = s;
+    int read = 0;
+    bool leading_dot = false;
+    if (*curr == '+' || *curr == '-') {
+        sign = *curr++;
+        if (curr != s_end && *curr == '.') leading_dot = true;
+    } else if (*curr == '.') {
+        leading_dot = true;
+    } else if (!IsDigit(*curr)) {
+        return false;
+    }
+    if (!leading_dot) {
+        while (curr != s_end && IsDigit(*curr)) {
+            mantissa *= 10;
+            mantissa += (int)(*curr - '0');
+            ++curr;
+            ++read;
+        }
+        if (read == 0) return false;
+    }
+    if (curr != s_end && *curr == '.') {
+        static const double kPow[] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+        // pow(10, -k) for the digits behind the table, computed once by the same library call
+        static const std::array<double, 40> kPowTail = [] {
+            std::array<double, 40> t{};
+            for (int k = 0; k < 40; k++) t[k] = std::pow(10.0, -k);
+            return t;
+        }();
+        ++curr;
+        read = 1;
+        while (curr != s_end && IsDigit(*curr)) {
+            mantissa += (int)(*curr - '0') * (read < 8 ? kPow[read] : (read < 40 ? kPowTail[read] : std::pow(10.0, -read)));
+            ++read;
+            ++curr;
+        }
+    } else if (curr != s_end && !(*curr == 'e' || *curr == 'E')) {
+        curr = s_end;          // trailing characters after the integer part end the number
+    }
+    if (curr != s_end && (*curr == 'e' || *curr == 'E')) {
+        ++curr;
+        if (curr != s_end && (*curr == '+' || *curr == '-')) exp_sign = *curr++;
+        else if (curr == s_end || !IsDigit(*curr)) return false;
+        read = 0;
+        while (curr != s_end && IsDigit(*curr)) {
+            if (exponent > 2147483647 / 10) return false;
+            exponent = exponent * 10 + (int)(*curr - '0');
+            ++curr;
+            ++read;
+        }
+        if (exp_sign == '-') exponent = -exponent;
+        if (read == 0) return false;
+    }
+    result = (sign == '+' ? 1 : -1) * (exponent ? std::ldexp(mantissa * std::pow(5.0, exponent), exponent) : mantissa);
+    return true;
+}
 inline float ParseFloat(const char *&p, float fallback = 0.0f) {
-    SkipSpace(p);
-    if (AtEol(p)) return fallback;
-    char *end;
-    float v = std::strtof(p, &end);
-    if (end == p) { while (!AtEol(p) && *p != ' ' && *p != '\t') ++p; return fallback; }
+    while (*p == ' ' || *p == '\t') ++p;
+    const char *end = p;
+    while (*end != '\0' && *end != '\n' && *end != ' ' && *end != '\t' && *end != '\r') ++end;
+    double v = fallback;
+    ParseRealToken(p, end, v);
     p = end;
-    return v;
+    return (float)v;
+}
+// decimal integer with optional sign; false when no digit follows
+inline bool ParseInt(const char *&p, long &out) {
+    const char *q = p;
+    bool neg = false;
+    if (*q == '+' || *q == '-') neg = *q++ == '-';
+    if (!IsDigit(*q)) return false;
+    long v = 0;
+    while (IsDigit(*q)) v = v * 10 + (*q++ - '0');
+    out = neg ? -v : v;
+    p = q;
+    return true;
 }
 inline std::string ParseRest(const char *&p) {
     SkipSpace(p);
@@ -95,35 +178,63 @@ struct ObjIndex {
     int v, vn, vt;
     bool operator==(const ObjIndex &o) const { return v == o.v && vn == o.vn && vt == o.vt; }
 };
-struct ObjIndexHash {
-    size_t operator()(const ObjIndex &i) const noexcept {
-        size_t h = std::hash<int>()(i.v);
-        h ^= std::hash<int>()(i.vn) + 0x9e3779b9 + (h << 6) + (h >> 2);
-        h ^= std::hash<int>()(i.vt) + 0x9e3779b9 + (h << 6) + (h >> 2);
-        return h;
+// (v, vn, vt) -> vertex number of one output mesh: open addressing over a power-of-two table,
+// grown at 50 % load.  The reference de-duplicates with a node-based hash map
+// (src/scene/loader.cpp:192-211); first-use order, which is what the mesh depends on, is the same.
+class VertexTable {
+public:
+    // returns the vertex number of `key`, or assigns `next` to it and reports `inserted`
+    uint32_t FindOrInsert(const ObjIndex &key, uint32_t next, bool &inserted) {
+        if ((count_ + 1) * 2 > slots_.size()) Grow();
+        size_t i = Hash(key) & (slots_.size() - 1);
+        for (;;) {
+            Slot &s = slots_[i];
+            if (s.value == kEmpty) { s.key = key; s.value = next; ++count_; inserted = true; return next; }
+            if (s.key == key) { inserted = false; return s.value; }
+            i = (i + 1) & (slots_.size() - 1);
+        }
     }
+private:
+    static constexpr uint32_t kEmpty = 0xffffffffu;
+    struct Slot { ObjIndex key; uint32_t value = kEmpty; };
+    static size_t Hash(const ObjIndex &k) {
+        uint64_t h = (uint64_t)(uint32_t)k.v * 0x9e3779b97f4a7c15ull;
+        h ^= ((uint64_t)(uint32_t)k.vn + 0x7f4a7c15u) * 0xc2b2ae3d27d4eb4full;
+        h ^= ((uint64_t)(uint32_t)k.vt + 0x165667b1u) * 0xff51afd7ed558ccdull;
+        return (size_t)(h ^ (h >> 29));
+    }
+public:
+    void Reserve(size_t keys) {                  // room for `keys` entries without growing
+        size_t want = 1024;
+        while (want < keys * 2) want *= 2;
+        if (want > slots_.size()) Grow(want);
+    }
+private:
+    void Grow(size_t to = 0) {
+        std::vector<Slot> old = std::move(slots_);
+        slots_.assign(to ? to : (old.empty() ? 1024 : old.size() * 2), Slot{});
+        count_ = 0;
+        bool inserted;
+        for (const Slot &s : old)
+            if (s.value != kEmpty) FindOrInsert(s.key, s.value, inserted);
+    }
+    std::vector<Slot> slots_;
+    size_t count_ = 0;
 };
 
-// one "v/vt/vn" corner; relative (negative) indices count back from the current array sizes
-bool ParseCorner(const char *&p, size_t nv, size_t nvt, size_t nvn, ObjIndex &out) {
+// one "v/vt/vn" corner as written: 1-based, or negative = counted back from the attributes read so far
+bool ParseRawCorner(const char *&p, long &v, long &vt, long &vn, bool &has_vt, bool &has_vn) {
     SkipSpace(p);
     if (AtEol(p)) return false;
-    auto fix = [](long idx, size_t n) -> int { return idx > 0 ? (int)idx - 1 : (idx < 0 ? (int)((long)n + idx) : -1); };
-    char *end;
-    long v = std::strtol(p, &end, 10);
-    if (end == p) return false;
-    p = end;
-    out = ObjIndex{fix(v, nv), -1, -1};
+    has_vt = has_vn = false;
+    vt = vn = 0;
+    if (!ParseInt(p, v)) return false;
     if (*p == '/') {
         ++p;
-        if (*p != '/') {
-            long t = std::strtol(p, &end, 10);
-            if (end != p) { out.vt = fix(t, nvt); p = end; }
-        }
+        if (*p != '/' && ParseInt(p, vt)) has_vt = true;
         if (*p == '/') {
             ++p;
-            long n = std::strtol(p, &end, 10);
-            if (end != p) { out.vn = fix(n, nvn); p = end; }
+            if (ParseInt(p, vn)) has_vn = true;
         }
     }
     return true;
@@ -331,7 +442,6 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
     if (!ReadFile(path, text)) return false;
     auto base_dir = path.parent_path();
 
-    std::vector<float> V, VN, VT;
     std::vector<MtlEntry> in_materials;
     std::unordered_map<std::string, int> material_index;
     std::vector<Shape> in_shapes;
@@ -342,57 +452,136 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
         cur = Shape();
     };
 
-    const char *p = text.c_str();
-    std::vector<ObjIndex> face;
-    while (*p) {
-        SkipSpace(p);
-        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
-            p += 1;
-            V.push_back(ParseFloat(p)); V.push_back(ParseFloat(p)); V.push_back(ParseFloat(p));
-        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
-            p += 2;
-            VN.push_back(ParseFloat(p)); VN.push_back(ParseFloat(p)); VN.push_back(ParseFloat(p));
-        } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
-            p += 2;
-            VT.push_back(ParseFloat(p)); VT.push_back(ParseFloat(p));
-        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
-            p += 1;
-            face.clear();
-            ObjIndex c;
-            while (ParseCorner(p, V.size() / 3, VT.size() / 2, VN.size() / 3, c)) face.push_back(c);
-            auto emit = [&](const ObjIndex &a, const ObjIndex &b, const ObjIndex &c3) {
-                cur.indices.push_back(a); cur.indices.push_back(b); cur.indices.push_back(c3);
-                cur.material_ids.push_back(cur_material);
-            };
-            bool valid = face.size() >= 3;
-            for (auto &i : face) valid = valid && i.v >= 0 && (size_t)i.v < V.size() / 3;
-            if (valid && face.size() == 3) {
-                emit(face[0], face[1], face[2]);
-            } else if (valid && face.size() == 4) {
-                // quads split along the shorter diagonal (tiny_obj_loader.h:1429-1517)
-                const float *v0 = &V[3 * face[0].v], *v1 = &V[3 * face[1].v], *v2 = &V[3 * face[2].v], *v3 = &V[3 * face[3].v];
-                float e02x = v2[0] - v0[0], e02y = v2[1] - v0[1], e02z = v2[2] - v0[2];
-                float e13x = v3[0] - v1[0], e13y = v3[1] - v1[1], e13z = v3[2] - v1[2];
-                float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
-                float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
-                if (sqr02 < sqr13) { emit(face[0], face[1], face[2]); emit(face[0], face[2], face[3]); }
-                else { emit(face[0], face[1], face[3]); emit(face[1], face[2], face[3]); }
-            } else if (valid) {
-                // larger polygons: triangle fan (convex input assumed; the reference ear-clips)
-                for (size_t k = 1; k + 1 < face.size(); k++) emit(face[0], face[k], face[k + 1]);
-            }
-        } else if (Keyword(p, "usemtl")) {
-            std::string name = ParseRest(p);
-            auto it = material_index.find(name);
-            cur_material = it == material_index.end() ? -1 : it->second;
-        } else if (Keyword(p, "mtllib")) {
-            std::string name = ParseRest(p);
-            ParseMtl(base_dir / name, in_materials, material_index);
-        } else if (Keyword(p, "o") || Keyword(p, "g")) {
-            flush();
-            cur.name = ParseRest(p);
+    // ---- pass 1, parallel: the text is cut at line ends into one piece per thread; each piece
+    // turns its lines into numbers without looking at the others.  Corner indices stay as written
+    // (relative ones count back from the attribute totals at their line, known only after the
+    // pieces are put together), statements that change state are kept as events in line order.
+    struct RawCorner { long v, vt, vn; bool has_vt, has_vn; };
+    struct Item {
+        enum Kind { kFace, kUseMtl, kMtlLib, kGroup } kind;
+        uint32_t first_corner = 0, num_corners = 0;         // kFace
+        uint32_t v_before = 0, vt_before = 0, vn_before = 0; // attributes of this piece read before the line
+        std::string text;                                    // the other kinds
+    };
+    struct Piece {
+        const char *begin = nullptr, *end = nullptr;
+        std::vector<float> V, VN, VT;
+        std::vector<RawCorner> corners;
+        std::vector<Item> items;
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t num_pieces = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), 16, text.size() / (1u << 20) + 1}));
+    std::vector<Piece> pieces(num_pieces);
+    {
+        const char *base = text.c_str(), *stop = base + text.size();
+        const char *cut = base;
+        for (size_t k = 0; k < num_pieces; k++) {
+            pieces[k].begin = cut;
+            const char *want = k + 1 == num_pieces ? stop : base + text.size() * (k + 1) / num_pieces;
+            if (want < cut) want = cut;
+            while (want < stop && *want != '\n') ++want;
+            if (want < stop) ++want;
+            pieces[k].end = cut = want;
         }
-        NextLine(p);
+    }
+    auto parse_piece = [](Piece &pc) {
+        const char *p = pc.begin;
+        while (p < pc.end) {
+            SkipSpace(p);
+            if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+                p += 1;
+                float x = ParseFloat(p), y = ParseFloat(p), z = ParseFloat(p);
+                pc.V.push_back(x); pc.V.push_back(y); pc.V.push_back(z);
+            } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+                p += 2;
+                float x = ParseFloat(p), y = ParseFloat(p), z = ParseFloat(p);
+                pc.VN.push_back(x); pc.VN.push_back(y); pc.VN.push_back(z);
+            } else if (p[0] == 'v' && p[1] == 't' && (p[2] == ' ' || p[2] == '\t')) {
+                p += 2;
+                float x = ParseFloat(p), y = ParseFloat(p);
+                pc.VT.push_back(x); pc.VT.push_back(y);
+            } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+                p += 1;
+                Item it;
+                it.kind = Item::kFace;
+                it.first_corner = (uint32_t)pc.corners.size();
+                it.v_before = (uint32_t)(pc.V.size() / 3); it.vt_before = (uint32_t)(pc.VT.size() / 2); it.vn_before = (uint32_t)(pc.VN.size() / 3);
+                RawCorner c;
+                while (ParseRawCorner(p, c.v, c.vt, c.vn, c.has_vt, c.has_vn)) pc.corners.push_back(c);
+                it.num_corners = (uint32_t)pc.corners.size() - it.first_corner;
+                pc.items.push_back(std::move(it));
+            } else if (Keyword(p, "usemtl")) {
+                Item it; it.kind = Item::kUseMtl; it.text = ParseRest(p); pc.items.push_back(std::move(it));
+            } else if (Keyword(p, "mtllib")) {
+                Item it; it.kind = Item::kMtlLib; it.text = ParseRest(p); pc.items.push_back(std::move(it));
+            } else if (Keyword(p, "o") || Keyword(p, "g")) {
+                Item it; it.kind = Item::kGroup; it.text = ParseRest(p); pc.items.push_back(std::move(it));
+            }
+            NextLine(p);
+        }
+    };
+    {
+        std::vector<std::thread> workers;
+        for (size_t k = 1; k < num_pieces; k++) workers.emplace_back(parse_piece, std::ref(pieces[k]));
+        parse_piece(pieces[0]);
+        for (auto &w : workers) w.join();
+    }
+
+    // ---- pass 2, in file order: attribute arrays joined, indices resolved, faces triangulated
+    std::vector<float> V, VN, VT;
+    {
+        size_t nv = 0, nn = 0, nt = 0;
+        for (auto &pc : pieces) { nv += pc.V.size(); nn += pc.VN.size(); nt += pc.VT.size(); }
+        V.reserve(nv); VN.reserve(nn); VT.reserve(nt);
+    }
+    std::vector<ObjIndex> face;
+    auto fix = [](long idx, size_t n) -> int { return idx > 0 ? (int)idx - 1 : (idx < 0 ? (int)((long)n + idx) : -1); };
+    for (auto &pc : pieces) {
+        const size_t v0 = V.size() / 3, vt0 = VT.size() / 2, vn0 = VN.size() / 3;     // totals before this piece
+        V.insert(V.end(), pc.V.begin(), pc.V.end());
+        VN.insert(VN.end(), pc.VN.begin(), pc.VN.end());
+        VT.insert(VT.end(), pc.VT.begin(), pc.VT.end());
+        for (auto &it : pc.items) {
+            if (it.kind == Item::kUseMtl) {
+                auto found = material_index.find(it.text);
+                cur_material = found == material_index.end() ? -1 : found->second;
+            } else if (it.kind == Item::kMtlLib) {
+                ParseMtl(base_dir / it.text, in_materials, material_index);
+            } else if (it.kind == Item::kGroup) {
+                flush();
+                cur.name = it.text;
+            } else {
+                // a face may only name attributes that precede it in the file (its totals at that line)
+                const size_t nv = v0 + it.v_before, nvt = vt0 + it.vt_before, nvn = vn0 + it.vn_before;
+                face.clear();
+                for (uint32_t k = 0; k < it.num_corners; k++) {
+                    const RawCorner &c = pc.corners[it.first_corner + k];
+                    face.push_back(ObjIndex{fix(c.v, nv), c.has_vn ? fix(c.vn, nvn) : -1, c.has_vt ? fix(c.vt, nvt) : -1});
+                }
+                auto emit = [&](const ObjIndex &a, const ObjIndex &b, const ObjIndex &c3) {
+                    cur.indices.push_back(a); cur.indices.push_back(b); cur.indices.push_back(c3);
+                    cur.material_ids.push_back(cur_material);
+                };
+                bool valid = face.size() >= 3;
+                for (auto &i : face) valid = valid && i.v >= 0 && (size_t)i.v < nv;
+                if (valid && face.size() == 3) {
+                    emit(face[0], face[1], face[2]);
+                } else if (valid && face.size() == 4) {
+                    // quads split along the shorter diagonal (tiny_obj_loader.h:1429-1517)
+                    const float *q0 = &V[3 * face[0].v], *q1 = &V[3 * face[1].v], *q2 = &V[3 * face[2].v], *q3 = &V[3 * face[3].v];
+                    float e02x = q2[0] - q0[0], e02y = q2[1] - q0[1], e02z = q2[2] - q0[2];
+                    float e13x = q3[0] - q1[0], e13y = q3[1] - q1[1], e13z = q3[2] - q1[2];
+                    float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
+                    float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+                    if (sqr02 < sqr13) { emit(face[0], face[1], face[2]); emit(face[0], face[2], face[3]); }
+                    else { emit(face[0], face[1], face[3]); emit(face[1], face[2], face[3]); }
+                } else if (valid) {
+                    // larger polygons: triangle fan (convex input assumed; the reference ear-clips)
+                    for (size_t k = 1; k + 1 < face.size(); k++) emit(face[0], face[k], face[k + 1]);
+                }
+            }
+        }
+        pc = Piece();        // release the piece's arrays
     }
     flush();
 
@@ -403,7 +592,7 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
         std::vector<V3> positions, normals;
         std::vector<V2> texcoords;
         std::vector<uint32_t> indices;
-        std::unordered_map<ObjIndex, size_t, ObjIndexHash> index_map;
+        VertexTable index_map;
         int material_id;
         std::shared_ptr<SceneObject> object;
     };
@@ -422,15 +611,17 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
                 auto md = std::make_unique<MeshData>();
                 md->material_id = material_id;
                 md->object = scene.AddObject(in_shape.name + "-" + mat_name);
+                md->index_map.Reserve(in_shape.indices.size() / 4);      // grows further if the mesh shares few vertices
+                md->indices.reserve(in_shape.indices.size());
                 mesh_data.push_back(std::move(md));
                 it = objects_map.insert({material_id, mesh_data.size() - 1}).first;
             }
             MeshData &data = *mesh_data[it->second];
             for (size_t i = 0; i < 3; i++) {
                 const ObjIndex &in_idx = in_shape.indices[3 * f + i];
-                auto found = data.index_map.find(in_idx);
-                if (found == data.index_map.end()) {
-                    found = data.index_map.emplace(in_idx, data.positions.size()).first;
+                bool inserted;
+                const uint32_t vertex = data.index_map.FindOrInsert(in_idx, (uint32_t)data.positions.size(), inserted);
+                if (inserted) {
                     data.positions.push_back(V3{V[3 * in_idx.v], V[3 * in_idx.v + 1], V[3 * in_idx.v + 2]});
                     if (has_normal) {
                         bool okn = in_idx.vn >= 0 && (size_t)in_idx.vn < VN.size() / 3;
@@ -441,7 +632,7 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
                         data.texcoords.push_back(okt ? V2{VT[2 * in_idx.vt], VT[2 * in_idx.vt + 1]} : V2{0.0f, 0.0f});
                     }
                 }
-                data.indices.push_back((uint32_t)found->second);
+                data.indices.push_back(vertex);
             }
         }
     }

@@ -72,6 +72,63 @@ def test_object_transforms_match_glm_vectors(cpt):
         sc.set_trs(5, [0, 0, 0], [0, 0, 0], [1, 1, 1])
 
 
+def test_large_obj_parsed_in_pieces_matches_independent_reader(cpt, tmp_path):
+    """A file big enough to be cut into several pieces for parallel parsing: attribute blocks,
+    groups and usemtl statements interleaved with faces, relative (negative) indices that refer
+    across piece boundaries, quads, numbers in every notation the reference's reader accepts."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    (tmp_path / "big.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\n\nnewmtl b\nKd 0.1 0.9 0.1\nKe 1 1 1\n")
+    lines = ["mtllib big.mtl"]
+    nv = 0
+    for block in range(60):
+        m = int(rng.integers(200, 1200))
+        pts = rng.uniform(-3, 3, (m, 3))
+        style = block % 4
+        for q in pts:
+            if style == 0:
+                lines.append("v %.9g %.9g %.9g" % tuple(q))
+            elif style == 1:
+                lines.append("v %.6e %.6e %.6e" % tuple(q))
+            elif style == 2:
+                lines.append("v\t%+.4f  %.3f %.7f\r" % tuple(q))
+            else:
+                lines.append("v %d %s %.12f" % (int(q[0]), ("%.3f" % q[1]).lstrip("0") if 0 < q[1] < 1 else "%.2f" % q[1], q[2]))
+            lines.append("vt %.5f %.5f" % tuple(rng.random(2)))
+            lines.append("vn %.4f %.4f %.4f" % tuple(rng.standard_normal(3)))
+        nv += m
+        if block % 7 == 0:
+            lines.append("g part%d" % block)
+        if block % 3 == 0:
+            lines.append("usemtl %s" % ("a", "b", "missing")[(block // 3) % 3])
+        for _ in range(int(rng.integers(300, 900))):
+            k = 4 if rng.random() < 0.3 else 3
+            if rng.random() < 0.5:          # absolute, anywhere in what has been read so far
+                ids = rng.integers(1, nv + 1, k)
+            else:                            # relative, reaching back into earlier blocks
+                ids = -rng.integers(1, min(nv, 5000) + 1, k)
+            lines.append("f " + " ".join("%d/%d/%d" % (i, i, i) for i in ids))
+    text = "\n".join(lines) + "\n"
+    while len(text) < 3_500_000:            # several pieces of at least 1 MiB
+        text += "# padding " + "x" * 100 + "\n"
+    (tmp_path / "big.obj").write_text(text)
+    sc = cpt.Scene().load_obj(str(tmp_path / "big.obj"), 2)
+    ref_objs = load_obj_scene(str(tmp_path / "big.obj"), 2)
+    objs = sc.objects()
+    assert [o["name"] for o in objs] == [o["name"] for o in ref_objs] and len(objs) > 5
+    for a, b in zip(objs, ref_objs):
+        for k in ("positions", "normals", "texcoords", "indices", "material"):
+            assert np.array_equal(a[k], b[k]), (a["name"], k)
+
+
+def test_number_grammar_of_the_reference_reader(cpt, tmp_path):
+    """tinyobjloader's tryParseDouble (tiny_obj_loader.h:866-996): what is not a number by its
+    grammar leaves the default 0, whatever strtof would make of it."""
+    (tmp_path / "n.obj").write_text("v 1 2 3\nv .5 -.25 +1.5e1\nv 1e 2 3\nv nan inf 0x10\nv 7. 1E-2 3e+0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\nf 3/1/1 4/1/1 5/1/1\n")
+    o = cpt.Scene().load_obj(str(tmp_path / "n.obj"), 2).objects()[0]
+    want = np.array([[1, 2, 3], [0.5, -0.25, 15.0], [0, 2, 3], [0, 0, 0], [7.0, 0.01, 3.0]], np.float32)
+    assert np.array_equal(o["positions"], want), o["positions"]
+
+
 def test_bsdf_type_flag_and_default_material(cpt, tmp_path):
     obj = tmp_path / "t.obj"
     obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 3/1/1 4/1/1\n")
