@@ -4,6 +4,7 @@ device and host sinf/cosf/powf (a handful of paths flip a decision).  Stated tol
 L2 error <= 1e-2 and per-channel mean within 1e-3 relative at 16 spp on a 64x64 image."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -154,6 +155,30 @@ def test_cli_renders_an_exr(cpt, tmp_path):
     objs, c = cornell(glass=False)
     ref, _ = OracleScene(objs, c).render(64, 48, 1, 33, 5)
     compare(img, ref)
+
+
+def test_cli_on_a_generated_scene_equals_the_in_memory_scene(cpt, tmp_path):
+    """scripts/gen_scene.py -> .obj/.mtl/.json -> the executable -> .exr, against the same triangles
+    handed over in memory: the file path re-indexes vertices but keeps the triangle order, so the
+    BVH, the random streams and therefore the film are the same bit for bit."""
+    prefix = tmp_path / "hf"
+    gen = os.path.join(ROOT, "scripts", "gen_scene.py")
+    r = subprocess.run([sys.executable, gen, "heightfield", "20000", str(prefix), "96", "64"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "hf_out"
+    r = subprocess.run([BINARY, str(prefix) + ".obj", str(prefix) + ".json", "--ui", "0", "--max-depth", "4", "--max-spp", "6", "-o", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img, _, _ = parse_exr(str(out) + ".exr")
+    objs, cam = synthetic_scene("heightfield", 20000)
+    objs[0]["material"] = material_block(dict(name="ground", Kd=[0.7] * 3, Ks=[0.0] * 3, Tf=[0.0] * 3, Ke=[0.0] * 3, Ni=1.0, Ns=1.0), 2)
+    objs[1]["material"] = material_block(dict(name="lamp", Kd=[0.0] * 3, Ks=[0.0] * 3, Tf=[0.0] * 3, Ke=[17.0, 12.0, 4.0], Ni=1.0, Ns=1.0), 2)
+    cam = dict(pos=[0.5, 0.3, 0.1], look_at=[0.5, 0.0, 0.45], up=[0, 1, 0], fov=40.0)
+    sc, tr = gpu_scene(cpt, objs, cam, 96, 64, max_depth=4)
+    tr.update(6)
+    mem = tr.film()
+    assert img.shape == mem.shape and (mem[..., :3] > 0).mean() > 0.5
+    assert np.array_equal(img.view(np.uint32), mem.view(np.uint32))
 
 
 @pytest.mark.parametrize("depth", [8, 0, 1, -1])
