@@ -92,6 +92,9 @@ _sig("cpt_tracer_reset_counters", C.c_int, [_vp])
 _sig("cpt_tracer_build_stage_ms", C.c_int, [_vp, _vp])
 _sig("cpt_selftest_division", C.c_int, [C.c_uint64, C.c_uint32, _vp])
 _sig("cpt_write_exr", C.c_int, [C.c_char_p, _f32, C.c_uint32, C.c_uint32])
+_sig("cpt_image_load", C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_size_t])
+_sig("cpt_image_save_png", C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32])
+_sig("cpt_scene_object_map", C.c_int, [_vp, C.c_uint32, C.c_int, _vp, _vp, _vp, C.c_size_t])
 
 
 class CptError(RuntimeError):
@@ -236,6 +239,16 @@ class Scene:
     def objects(self):
         return [self.object(i) for i in range(self.num_objects())]
 
+    def object_map(self, index, which):
+        """RGBA8 map of the object's material as (h, w) uint32, or None: which = 0 diffuse, 1 specular, 2 emission."""
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        check(lib.cpt_scene_object_map(self.h, index, which, C.byref(w), C.byref(h), None, 0))
+        if w.value == 0:
+            return None
+        out = np.zeros((h.value, w.value), dtype=np.uint32)
+        check(lib.cpt_scene_object_map(self.h, index, which, C.byref(w), C.byref(h), out.ctypes.data, out.size))
+        return out
+
     def set_trs(self, index, translate, rotate_degrees, scale):
         t, r, s = (np.ascontiguousarray(v, dtype=np.float32) for v in (translate, rotate_degrees, scale))
         check(lib.cpt_scene_object_set_trs(self.h, index, t.ctypes.data, r.ctypes.data, s.ctypes.data))
@@ -379,3 +392,17 @@ def write_exr(path, rgba):
     rgba = np.ascontiguousarray(rgba, dtype=np.float32)
     h, w = rgba.shape[0], rgba.shape[1]
     check(lib.cpt_write_exr(os.fsencode(path), rgba.reshape(-1), w, h))
+
+
+def load_image(path):
+    """PNG / PPM / PGM file -> (h, w) uint32 RGBA8 (red in the low byte)."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    check(lib.cpt_image_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value), dtype=np.uint32)
+    check(lib.cpt_image_load(os.fsencode(path), C.byref(w), C.byref(h), out.ctypes.data, out.size))
+    return out
+
+
+def save_png(path, rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint32)
+    check(lib.cpt_image_save_png(os.fsencode(path), rgba.ctypes.data, rgba.shape[1], rgba.shape[0]))

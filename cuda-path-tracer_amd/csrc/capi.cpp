@@ -468,6 +468,47 @@ int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches) {
     });
 }
 
+int cpt_image_load(const char *path, uint32_t *width, uint32_t *height, uint32_t *rgba, size_t capacity) {
+    if (!path || !width || !height) return Fail(CPT_ERR_INVALID, "cpt_image_load: null argument");
+    return Guard([&] {
+        std::string error;
+        auto image = LoadImage(path, error);
+        if (!image) return Fail(CPT_ERR_IO, error);
+        *width = image->width;
+        *height = image->height;
+        if (rgba) {
+            if (capacity < image->rgba.size()) return Fail(CPT_ERR_INVALID, "cpt_image_load: buffer too small");
+            memcpy(rgba, image->rgba.data(), image->rgba.size() * sizeof(uint32_t));
+        }
+        return (int)CPT_OK;
+    });
+}
+
+int cpt_image_save_png(const char *path, const uint32_t *rgba, uint32_t width, uint32_t height) {
+    if (!path || !rgba || width == 0 || height == 0) return Fail(CPT_ERR_INVALID, "cpt_image_save_png: bad argument");
+    return Guard([&] {
+        Image image;
+        image.width = width;
+        image.height = height;
+        image.rgba.assign(rgba, rgba + (size_t)width * height);
+        return SavePng(path, image) ? (int)CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'");
+    });
+}
+
+int cpt_scene_object_map(const cpt_scene *s, uint32_t index, int which, uint32_t *width, uint32_t *height, uint32_t *rgba, size_t capacity) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj || !width || !height || which < 0 || which > 2) return Fail(CPT_ERR_INVALID, "cpt_scene_object_map: bad argument");
+    const Material *mat = obj->GetComponent<MaterialComponent>()->GetMaterial();
+    const std::shared_ptr<Image> &image = which == 0 ? mat->diffuse_image : (which == 1 ? mat->specular_image : mat->emission_image);
+    *width = image ? image->width : 0;
+    *height = image ? image->height : 0;
+    if (image && rgba) {
+        if (capacity < image->rgba.size()) return Fail(CPT_ERR_INVALID, "cpt_scene_object_map: buffer too small");
+        memcpy(rgba, image->rgba.data(), image->rgba.size() * sizeof(uint32_t));
+    }
+    return CPT_OK;
+}
+
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height) {
     if (!path || !rgba) return Fail(CPT_ERR_INVALID, "cpt_write_exr: null argument");
     return WriteExrRgba(path, rgba, width, height) ? CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'");

@@ -71,6 +71,8 @@ enum LobeType : int { kLobeNone = 0, kLobeDiffuse = 1, kLobeGlossy = 2, kLobeSpe
 // BSDF parameter block per material, evaluated once on the host from the MTL values
 // (src/kernels/material/mtl.cuh:16-66 has no uv dependence without textures).
 // Glass keeps reflectance in `diffuse` and transmittance in `specular`.
+// Texture numbers are 1-based indices into SceneDev::textures, 0 = constant.  A material with a
+// diffuse or specular map keeps the raw constants here and is finished per hit (material_at()).
 struct BsdfDev {
     int type;
     V3 emission;
@@ -78,7 +80,14 @@ struct BsdfDev {
     V3 specular;
     V3 transmittance;
     float shininess, s_norm, ior, roughness, opacity;
-    float pad[2];
+    uint32_t tex_diffuse_specular;     // diffuse map | specular map << 16
+    uint32_t tex_emission;
+};
+
+// RGBA8 image, sRGB encoded, row 0 = first row of the file (CuTexture, src/cuda_helpers/texture.cpp:5-27)
+struct TextureDev {
+    const uint32_t *texels;
+    uint32_t width, height;
 };
 static_assert(sizeof(BsdfDev) == 80, "five 16 B loads");
 
@@ -103,6 +112,8 @@ struct SceneDev {
     const InstanceDev *instances;
     const MeshDev *meshes;
     const BsdfDev *materials;
+    const TextureDev *textures; // may be null when no material names a map
+    const float *srgb_to_linear; // 256 entries, shared by every texture fetch
     const uint32_t *lights;     // instance index of each light
     uint32_t num_lights;
     float light_pick_pdf;

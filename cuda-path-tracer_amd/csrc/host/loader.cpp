@@ -663,8 +663,16 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
         mat->diffuse_map = in_mat.diffuse_tex;
         mat->specular_map = in_mat.specular_tex;
         mat->emission_map = in_mat.emissive_tex;
-        if (!in_mat.diffuse_tex.empty() || !in_mat.specular_tex.empty() || !in_mat.emissive_tex.empty())
-            std::cout << "warning: material '" << in_mat.name << "' names texture maps; textures are not sampled, constants are used" << std::endl;
+        // LoadTexture, src/scene/loader.cpp:71-97; a map that cannot be read leaves the constant in place
+        auto load_map = [&](std::shared_ptr<Image> &image, const std::string &name) {
+            if (name.empty()) return;
+            std::string error;
+            image = LoadImage(base_dir / name, error);
+            if (!image) std::cout << "warning: material '" << in_mat.name << "': " << error << "; the constant is used" << std::endl;
+        };
+        load_map(mat->diffuse_image, in_mat.diffuse_tex);
+        load_map(mat->specular_image, in_mat.specular_tex);
+        load_map(mat->emission_image, in_mat.emissive_tex);
         mat->SetChanged();
         materials[i] = mat;
     }

@@ -161,6 +161,18 @@ void PathTracer::BuildInstancesAndLights() {
     std::vector<uint32_t> lights;
     std::unordered_map<const Material *, uint32_t> material_index;
     uint32_t slot = 0;
+    // one device texture per distinct image, numbered from 1
+    std::vector<const Image *> images;
+    std::unordered_map<const Image *, uint32_t> image_index;
+    auto texture_number = [&](const std::shared_ptr<Image> &image) -> uint32_t {
+        if (!image || image->rgba.empty()) return 0u;
+        auto found = image_index.find(image.get());
+        if (found == image_index.end()) {
+            images.push_back(image.get());
+            found = image_index.emplace(image.get(), (uint32_t)images.size()).first;
+        }
+        return found->second;
+    };
 
     scene_.ForEach<const MeshComponent, const MaterialComponent>([&](SceneObject &object, const MeshComponent &mesh, const MaterialComponent &material) {
         if (mesh.GetMesh()->IndicesCount() / 3 == 0) return;
@@ -169,7 +181,8 @@ void PathTracer::BuildInstancesAndLights() {
         if (found == material_index.end()) {
             found = material_index.emplace(mat, (uint32_t)materials.size()).first;
             materials.push_back(cpt::make_bsdf(mat->emission, mat->diffuse, mat->specular, mat->transmittance, mat->shininess, mat->ior, mat->opacity,
-                                               mat->bsdf_type));
+                                               mat->bsdf_type, texture_number(mat->diffuse_image), texture_number(mat->specular_image),
+                                               texture_number(mat->emission_image)));
         }
         cpt::InstanceDev inst;
         memset(&inst, 0, sizeof(inst));
@@ -193,6 +206,31 @@ void PathTracer::BuildInstancesAndLights() {
     if (!lights.empty()) light_table_.Allocate(sizeof(uint32_t) * lights.size(), lights.data(), stream_);
     counters_.Allocate(sizeof(cpt::Counters) * cpt::kCounterSlots);
     counters_.Zero(stream_);
+    if (images.size() > 0xffffu) throw std::runtime_error("more than 65535 distinct material maps");
+    scene_dev_.textures = nullptr;
+    scene_dev_.srgb_to_linear = nullptr;
+    if (!images.empty()) {
+        std::vector<uint32_t> all;
+        std::vector<size_t> first;
+        for (const Image *im : images) {
+            first.push_back(all.size());
+            all.insert(all.end(), im->rgba.begin(), im->rgba.end());
+        }
+        texel_pool_.Allocate(all.size() * sizeof(uint32_t), all.data(), stream_);
+        const uint32_t *pool = texel_pool_.TypedGpuData<uint32_t>();
+        std::vector<cpt::TextureDev> table;
+        for (size_t k = 0; k < images.size(); k++) table.push_back(cpt::TextureDev{pool + first[k], images[k]->width, images[k]->height});
+        texture_table_.Allocate(sizeof(cpt::TextureDev) * table.size(), table.data(), stream_);
+        // sRGB electro-optical transfer function (IEC 61966-2-1) for the 256 codes
+        float lut[256];
+        for (int c = 0; c < 256; c++) {
+            const float s = (float)c / 255.0f;
+            lut[c] = s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f);
+        }
+        srgb_table_.Allocate(sizeof(lut), lut, stream_);
+        scene_dev_.textures = texture_table_.TypedGpuData<cpt::TextureDev>();
+        scene_dev_.srgb_to_linear = srgb_table_.TypedGpuData<float>();
+    }
 
     scene_dev_.instances = instance_table_.TypedGpuData<cpt::InstanceDev>();
     scene_dev_.materials = material_table_.TypedGpuData<cpt::BsdfDev>();

@@ -102,6 +102,7 @@ private:
     cpt::HipBuffer leaf_scratch_;
     cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_;
     cpt::HipBuffer mesh_table_, instance_table_, material_table_, light_table_, counters_;
+    cpt::HipBuffer texel_pool_, texture_table_, srgb_table_;
     uint32_t num_lights_ = 0;
     cpt::SceneDev scene_dev_{};
 };

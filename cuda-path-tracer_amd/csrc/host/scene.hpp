@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../vecmath.h"
+#include "image.hpp"
 
 struct Bbox {                                     // src/scene/bbox.hpp
     cpt::V3 pmin{3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
@@ -73,8 +74,10 @@ public:
     float shininess = 1.0f;
     float opacity = 1.0f;
     int bsdf_type = 2;
-    // texture file names as the MTL gives them; sampling them is not implemented on the device yet
+    // material maps: file names as the MTL gives them and the decoded images (null = constant);
+    // the reference loads diffuse, specular and emissive maps (src/scene/loader.cpp:245-247)
     std::string emission_map, diffuse_map, specular_map;
+    std::shared_ptr<Image> emission_image, diffuse_image, specular_image;
     uint32_t revision = 0;
 };
 

@@ -6,20 +6,24 @@
 
 namespace cpt {
 
-struct Surface { Vertex vertex; BsdfDev bsdf; int32_t light; };
+struct Surface { Vertex vertex; BsdfDev bsdf; int32_t light; };     // vertex.texcoord is valid when the material reads it
 
-// src/kernels/scene/instance.cuh:19-26
+// src/kernels/scene/instance.cuh:19-26.  MAPS = false is the variant for scenes without material maps: no
+// texture coordinates, no per-hit material evaluation (kernels are built both ways, the host picks).
+template <bool MAPS>
 __device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit, LaneCounters &cnt) {
     cnt.shades++;
     const InstanceDev &in = sc.instances[hit.inst];
     const MeshDev &m = sc.meshes[in.mesh];
     Surface s;
-    s.vertex = get_vertex(m, hit.prim, hit.u, hit.v);
+    const BsdfDev &material = sc.materials[in.material];
+    const bool mapped = MAPS && material_reads_texcoord(material);
+    s.vertex = get_vertex(m, hit.prim, hit.u, hit.v, mapped);
     M4 tr = in.transform;
     vertex_transform_pdf(s.vertex, tr);
     s.vertex.position = xyz(mul(tr, v4(s.vertex.position, 1.0f)));
     s.vertex.normal = xyz(normalize4(mul(in.transform_it, v4(s.vertex.normal, 0.0f))));   // 4-component normalise, as the reference writes it
-    s.bsdf = sc.materials[in.material];
+    s.bsdf = mapped ? material_at(material, sc.textures, sc.srgb_to_linear, s.vertex.texcoord) : material;
     s.light = in.light;
     return s;
 }
@@ -27,10 +31,13 @@ __device__ inline Surface shading_surface(const SceneDev &sc, const Hit &hit, La
 struct LightSample { V3 dir; float pdf; V3 weight; float dist; };
 
 // src/kernels/geometry/geometry.cuh:27-39 + src/kernels/light/geometry.cuh:17-30
+template <bool MAPS>
 __device__ inline LightSample light_sample(const SceneDev &sc, uint32_t inst_id, V3 pos, V2 rand) {
     const InstanceDev &in = sc.instances[inst_id];
     const MeshDev &m = sc.meshes[in.mesh];
-    Vertex vert = sample_vertex(m, rand);
+    const BsdfDev &material = sc.materials[in.material];
+    const bool mapped = MAPS && material.tex_emission != 0u;
+    Vertex vert = sample_vertex(m, rand, mapped);
     M4 tr = in.transform;
     vertex_transform_pdf(vert, tr);
     vert.position = xyz(mul(tr, v4(vert.position, 1.0f)));
@@ -44,7 +51,9 @@ __device__ inline LightSample light_sample(const SceneDev &sc, uint32_t inst_id,
     ls.dist = dist;
     float cos_theta = dot(-dir, vert.normal);
     ls.pdf = cos_theta > 0.0f ? vert.pdf * dist_sqr / cos_theta : 0.0f;
-    ls.weight = sc.materials[in.material].emission / ls.pdf;
+    V3 emission = material.emission;       // material.ptr->emission.At(vert.texcoord)
+    if (mapped) emission = texture_fetch(sc.textures[material.tex_emission - 1], sc.srgb_to_linear, vert.texcoord.x, 1.0f - vert.texcoord.y);
+    ls.weight = emission / ls.pdf;
     return ls;
 }
 

@@ -19,6 +19,7 @@ struct PathLane {
 // One trip for the whole wave: closest-hit trace for every live lane (camera rays and bounce rays
 // mixed), shading + light sampling, any-hit trace for the lanes with a shadow ray, BSDF sampling,
 // film write for the lanes whose path ended.  Every lane of the wave must call it.
+template <bool MAPS>
 __device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, PathLane &l, TraceStack &st, LaneCounters &cnt) {
     // ---- extend
     Hit hit;
@@ -30,11 +31,12 @@ __device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, Path
     V3 pos = v3(0.0f), normal = v3(0.0f, 0.0f, 1.0f), ldir = v3(0.0f), lweight = v3(0.0f);
     float lpdf = 0.0f, ldist = 0.0f;
     uint32_t material = 0;
+    V2 uv = V2{0.0f, 0.0f};
     if (l.alive) {
         if (!got) {
             finish = true;
         } else {
-            Surface surface = shading_surface(sc, hit, cnt);
+            Surface surface = shading_surface<MAPS>(sc, hit, cnt);
             if (l.primary) {
                 l.primary = false;
                 if (p.channel == 1) { l.color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
@@ -58,11 +60,12 @@ __device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, Path
                 pos = surface.vertex.position;
                 normal = surface.vertex.normal;
                 material = sc.instances[hit.inst].material;
+                if (MAPS) uv = surface.vertex.texcoord;
                 if (!bsdf_is_delta(surface.bsdf)) {
                     float r1 = l.sampler.next1d();
                     uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
                     V2 r2 = l.sampler.next2d();
-                    LightSample ls = light_sample(sc, sc.lights[index], pos, r2);
+                    LightSample ls = light_sample<MAPS>(sc, sc.lights[index], pos, r2);
                     ls.pdf *= sc.light_pick_pdf;
                     ls.weight = ls.weight / sc.light_pick_pdf;
                     if (ls.pdf > 0.0f) { need_shadow = true; ldir = ls.dir; lweight = ls.weight; lpdf = ls.pdf; ldist = ls.dist; }
@@ -78,7 +81,7 @@ __device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, Path
 
     // ---- light contribution and next direction (path.cu:38-55)
     if (l.alive && !finish) {
-        const BsdfDev bsdf = sc.materials[material];
+        const BsdfDev bsdf = MAPS ? material_at(sc.materials[material], sc.textures, sc.srgb_to_linear, uv) : sc.materials[material];
         Frame frame = Frame::from_normal(normal);
         V3 wo = frame.to_local(-l.rd);
         if (need_shadow && !occluded) {

@@ -13,11 +13,12 @@ namespace cpt {
 namespace {
 
 // src/kernels/integrator/path.cu:9-83
+template <bool MAPS>
 __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, TraceStack &st, LaneCounters &cnt) {
     Hit hit;
     float tmax = kRayTMax;
     if (!trace<false>(sc, true, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
-    Surface surface = shading_surface(sc, hit, cnt);
+    Surface surface = shading_surface<MAPS>(sc, hit, cnt);
     if (channel == 1) return surface.vertex.normal * 0.5f + v3(0.5f);
     V3 color = surface.bsdf.emission;
     if (!is_zero(color)) return color;
@@ -30,7 +31,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
             float r1 = sampler.next1d();
             uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);   // light/light.cuh:39-43
             V2 r2 = sampler.next2d();
-            LightSample ls = light_sample(sc, sc.lights[index], surface.vertex.position, r2);
+            LightSample ls = light_sample<MAPS>(sc, sc.lights[index], surface.vertex.position, r2);
             ls.pdf *= sc.light_pick_pdf;
             ls.weight = ls.weight / sc.light_pick_pdf;
             if (ls.pdf > 0.0f) {
@@ -55,7 +56,7 @@ __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampl
         tmax = kRayTMax;
         if (!trace<false>(sc, true, ro, rd, kRayTMin, tmax, hit, st, cnt)) break;
 
-        surface = shading_surface(sc, hit, cnt);
+        surface = shading_surface<MAPS>(sc, hit, cnt);
         if (!is_zero(surface.bsdf.emission) && dot(rd, surface.vertex.normal) < 0.0f) {
             float mis_weight = 1.0f;
             if (bs.lobe != kLobeSpecular) {
@@ -83,6 +84,7 @@ __device__ inline uint32_t xcd_band_remap(uint32_t b, uint32_t nb) {
 }
 
 // one workgroup = one 16x16 pixel tile, one wave = one 8x8 sub-tile
+template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParams p) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
         uint32_t pixel_index;
         V3 ro, rd;
         pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, sampler, pixel_index, ro, rd);
-        V3 color = trace_path(sc, ro, rd, sampler, p.max_depth, p.channel, st, cnt);
+        V3 color = trace_path<MAPS>(sc, ro, rd, sampler, p.max_depth, p.channel, st, cnt);
         film_accumulate(p, pixel_index, color);
     }
     flush_counters(sc, cnt, active ? 1u : 0u, s_cnt);
@@ -112,6 +114,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
 // out one 8x8 tile at a time (SegmentFetch: a cursor per XCD over a contiguous band of tiles, so
 // neighbouring tiles share an L2); idle lanes are found with a ballot and numbered with a popcount
 // prefix.  One trip of the loop is path_trip().
+template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
         }
         if (__ballot(l.alive) == 0ull) break;        // nothing in flight and every tile is handed out
 
-        path_trip(sc, p, l, st, cnt);
+        path_trip<MAPS>(sc, p, l, st, cnt);
     }
     flush_counters(sc, cnt, paths, s_cnt);
 }
@@ -257,7 +260,8 @@ int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_misma
 int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream) {
     uint32_t tiles = ((p.width + 15) / 16) * ((p.height + 15) / 16);
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_render, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
+    if (sc.textures) hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
+    else hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
     return (int)hipGetLastError();
 }
 
@@ -266,13 +270,14 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     if (tiles == 0) return 0;
     uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? want : max_blocks;
-    hipLaunchKernelGGL(k_render_regen, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
+    if (sc.textures) hipLaunchKernelGGL(k_render_regen<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
+    else hipLaunchKernelGGL(k_render_regen<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
     return (int)hipGetLastError();
 }
 
 int render_regen_resident_blocks(int device) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_regen, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_regen<true>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return per_cu * cus;
 }

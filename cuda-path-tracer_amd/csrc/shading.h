@@ -49,7 +49,7 @@ struct Frame {
     CPT_HD V3 to_world(V3 p) const { return x * p.x + y * p.y + z * p.z + v3(0.0f); }         // :30-32
 };
 
-struct Vertex { V3 position, normal; float pdf; };
+struct Vertex { V3 position, normal; float pdf; V2 texcoord; };
 
 // src/kernels/geometry/common.cuh:15-20
 CPT_HD void vertex_transform_pdf(Vertex &v, const M4 &transform) {
@@ -59,8 +59,8 @@ CPT_HD void vertex_transform_pdf(Vertex &v, const M4 &transform) {
     v.pdf /= length(cross(t, b));
 }
 
-// src/kernels/geometry/trimesh.cuh:45-72 (texture coordinates are not fetched: no material reads them)
-CPT_D Vertex get_vertex(const MeshDev &m, uint32_t prim, float ax, float ay) {
+// src/kernels/geometry/trimesh.cuh:45-72; texture coordinates are fetched only for materials that read them
+CPT_D Vertex get_vertex(const MeshDev &m, uint32_t prim, float ax, float ay, bool want_texcoord = false) {
     uint32_t i0 = m.indices[prim * 3], i1 = m.indices[prim * 3 + 1], i2 = m.indices[prim * 3 + 2];
     Vertex vert;
     V3 pos0 = m.positions[i0], pos1 = m.positions[i1], pos2 = m.positions[i2];
@@ -70,6 +70,11 @@ CPT_D Vertex get_vertex(const MeshDev &m, uint32_t prim, float ax, float ay) {
     vert.position = pos0 + ax * (pos1 - pos0) + ay * (pos2 - pos0);
     V3 n0 = m.normals[i0], n1 = m.normals[i1], n2 = m.normals[i2];
     vert.normal = normalize(n0 + ax * (n1 - n0) + ay * (n2 - n0));
+    vert.texcoord = V2{0.0f, 0.0f};
+    if (want_texcoord) {
+        V2 t0 = m.texcoords[i0], t1 = m.texcoords[i1], t2 = m.texcoords[i2];
+        vert.texcoord = t0 + ax * (t1 - t0) + ay * (t2 - t0);
+    }
     return vert;
 }
 
@@ -81,13 +86,13 @@ CPT_HD uint32_t f2u_sat(float f) {
 }
 
 // trimesh.cuh:74-80: uniform triangle, then uniform point on it
-CPT_D Vertex sample_vertex(const MeshDev &m, V2 rand) {
+CPT_D Vertex sample_vertex(const MeshDev &m, V2 rand, bool want_texcoord = false) {
     float nt = (float)m.num_triangles;
     uint32_t prim = min(f2u_sat(rand.x * nt), m.num_triangles - 1);
     float u_sqrt = sqrtf(rand.x * nt - (float)prim);
     float u = 1.0f - u_sqrt;
     float v = (1.0f - rand.y) * u_sqrt;
-    return get_vertex(m, prim, u, v);
+    return get_vertex(m, prim, u, v, want_texcoord);
 }
 
 // ------------------------------------------------------------------ BSDFs (src/kernels/bsdf/*.cuh)
@@ -389,11 +394,58 @@ CPT_HD V3 bsdf_eval(const BsdfDev &b, V3 wo, V3 wi) {
     }
 }
 
+// ------------------------------------------------------------------ textures
+// What tex2D<float4> returns for the reference's texture objects (src/cuda_helpers/texture.cpp:
+// normalised coordinates, wrap addressing, linear filtering, sRGB texels read as normalised
+// floats): texel centres at (i + 0.5) / size, the two nearest texels per axis blended with the
+// fractional distance kept to 8 bits (the fixed-point weights of the CUDA programming guide's
+// texture-fetching appendix), sRGB decoded per texel before the blend.  The decode table is built
+// once on the host so that every user of it sees the same 256 floats.
+CPT_HD float wrap_unit(float x) { return x - floorf(x); }
+CPT_D V3 texture_fetch(const TextureDev &t, const float *srgb_to_linear, float u, float v) {
+    const float x = wrap_unit(u) * (float)t.width - 0.5f, y = wrap_unit(v) * (float)t.height - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = floorf((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f), b = floorf((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int w = (int)t.width, h = (int)t.height;
+    int x0 = (int)fx % w, y0 = (int)fy % h;
+    if (x0 < 0) x0 += w;
+    if (y0 < 0) y0 += h;
+    const int x1 = x0 + 1 == w ? 0 : x0 + 1, y1 = y0 + 1 == h ? 0 : y0 + 1;
+    const uint32_t t00 = t.texels[y0 * w + x0], t10 = t.texels[y0 * w + x1], t01 = t.texels[y1 * w + x0], t11 = t.texels[y1 * w + x1];
+    auto channel = [&](int shift) {
+        const float c00 = srgb_to_linear[(t00 >> shift) & 255u], c10 = srgb_to_linear[(t10 >> shift) & 255u];
+        const float c01 = srgb_to_linear[(t01 >> shift) & 255u], c11 = srgb_to_linear[(t11 >> shift) & 255u];
+        return (1.0f - a) * (1.0f - b) * c00 + a * (1.0f - b) * c10 + (1.0f - a) * b * c01 + a * b * c11;
+    };
+    return V3{channel(0), channel(8), channel(16)};
+}
+
+// MaterialValue::At for every mapped value of a material (src/kernels/material/common.cuh:15-27:
+// the map replaces the constant and is read at (u, 1 - v)), then the part of MtlMaterial::GetBsdf
+// that depends on those values (src/kernels/material/mtl.cuh:29-58).
+CPT_D BsdfDev material_at(const BsdfDev &m, const TextureDev *textures, const float *srgb_to_linear, V2 uv) {
+    BsdfDev b = m;
+    if ((m.tex_diffuse_specular | m.tex_emission) == 0u) return b;
+    if (m.tex_emission) b.emission = texture_fetch(textures[m.tex_emission - 1], srgb_to_linear, uv.x, 1.0f - uv.y);
+    const uint32_t td = m.tex_diffuse_specular & 0xffffu, ts = m.tex_diffuse_specular >> 16;
+    if (b.type != kGlass && (td | ts) != 0u) {
+        if (td) b.diffuse = texture_fetch(textures[td - 1], srgb_to_linear, uv.x, 1.0f - uv.y);
+        if (ts) b.specular = texture_fetch(textures[ts - 1], srgb_to_linear, uv.x, 1.0f - uv.y);
+        if (b.type == kPhong || b.type == kBlinnPhong) b.diffuse = b.diffuse * (1.0f - fmaxf(b.specular.x, fmaxf(b.specular.y, b.specular.z)));
+    }
+    return b;
+}
+CPT_HD bool material_reads_texcoord(const BsdfDev &m) { return (m.tex_diffuse_specular | m.tex_emission) != 0u; }
+
 // Host-side evaluation of the MTL material into a BSDF block
 // (src/kernels/material/material.cuh:15-27 and src/kernels/material/mtl.cuh:16-66).
-inline BsdfDev make_bsdf(V3 emission, V3 diffuse, V3 specular, V3 transmittance, float shininess, float ior, float opacity, int bsdf_type) {
+// tex_diffuse / tex_specular / tex_emission: 1-based texture numbers or 0.  With a diffuse or
+// specular map the Phong-family scaling of the diffuse colour is left to material_at().
+inline BsdfDev make_bsdf(V3 emission, V3 diffuse, V3 specular, V3 transmittance, float shininess, float ior, float opacity, int bsdf_type,
+                         uint32_t tex_diffuse = 0, uint32_t tex_specular = 0, uint32_t tex_emission = 0) {
     BsdfDev b;
     memset(&b, 0, sizeof(b));
+    const bool mapped = (tex_diffuse | tex_specular) != 0;
     if (bsdf_type != kMicrofacet && opacity == 0.0f) {
         b.type = kGlass;
         b.specular = transmittance;
@@ -405,13 +457,13 @@ inline BsdfDev make_bsdf(V3 emission, V3 diffuse, V3 specular, V3 transmittance,
             case kLambert: b.diffuse = diffuse; break;
             case kPhong:
                 b.diffuse = diffuse; b.specular = specular;
-                b.diffuse = b.diffuse * (1.0f - fmaxf(b.specular.x, fmaxf(b.specular.y, b.specular.z)));
+                if (!mapped) b.diffuse = b.diffuse * (1.0f - fmaxf(b.specular.x, fmaxf(b.specular.y, b.specular.z)));
                 b.shininess = shininess;
                 b.s_norm = (shininess + 1) * kInv2Pi;
                 break;
             case kBlinnPhong:
                 b.diffuse = diffuse; b.specular = specular;
-                b.diffuse = b.diffuse * (1.0f - fmaxf(b.specular.x, fmaxf(b.specular.y, b.specular.z)));
+                if (!mapped) b.diffuse = b.diffuse * (1.0f - fmaxf(b.specular.x, fmaxf(b.specular.y, b.specular.z)));
                 b.shininess = shininess;
                 b.s_norm = (shininess + 2) / (4 * kPi * (2 - powf(2.0f, -shininess / 2)));
                 break;
@@ -424,6 +476,8 @@ inline BsdfDev make_bsdf(V3 emission, V3 diffuse, V3 specular, V3 transmittance,
         }
     }
     b.emission = emission;
+    b.tex_diffuse_specular = b.type == kGlass ? 0u : (tex_diffuse | (tex_specular << 16));
+    b.tex_emission = tex_emission;
     return b;
 }
 

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueueTraceWaves) k_wf_trace(Scen
 // Everything the integrator does between two rays of one path (path.cu:12-80 in the order the
 // statements run for one path): primary-hit special cases, emitter hit with MIS, Russian roulette,
 // depth test, light sample (shadow ray + pending contribution), BSDF sample (next ray).
+template <bool MAPS>
 __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, WavefrontBuffers wb, uint32_t bounce_id) {
     __shared__ unsigned long long s_cnt[5];
     LaneCounters cnt;
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
             if (hit.inst == 0xffffffffu) {
                 finish = true;
             } else {
-                Surface surface = shading_surface(sc, hit, cnt);
+                Surface surface = shading_surface<MAPS>(sc, hit, cnt);
                 if (primary) {
                     primary = false;
                     if (p.channel == 1) { color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
                         float r1 = sampler.next1d();
                         uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
                         V2 r2 = sampler.next2d();
-                        LightSample ls = light_sample(sc, sc.lights[index], pos, r2);
+                        LightSample ls = light_sample<MAPS>(sc, sc.lights[index], pos, r2);
                         ls.pdf *= sc.light_pick_pdf;
                         ls.weight = ls.weight / sc.light_pick_pdf;
                         if (ls.pdf > 0.0f) {
@@ -232,6 +233,7 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
 
 // Finishes what the queue still holds: lanes load a queued path's state and run it to its end
 // in registers, picking up another queued path whenever one ends.
+template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, Rende
             idle = __ballot(!l.alive);
         }
         if (__ballot(l.alive) == 0ull) break;
-        path_trip(sc, p, l, st, cnt);
+        path_trip<MAPS>(sc, p, l, st, cnt);
     }
     flush_counters(sc, cnt, 0u, s_cnt);
 }
@@ -293,8 +295,8 @@ int wavefront_resident_blocks(int device) {
 }
 
 int wavefront_finish_resident_blocks(int device) {
-    const void *kernels[1] = {(const void *)k_wf_finish};
-    return resident_blocks_of(kernels, 1, device);
+    const void *kernels[2] = {(const void *)k_wf_finish<false>, (const void *)k_wf_finish<true>};
+    return resident_blocks_of(kernels, 2, device);
 }
 
 static uint32_t persistent_blocks(const WavefrontBuffers &wb, uint32_t resident_blocks) {
@@ -315,13 +317,15 @@ int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontB
     const uint32_t blocks = persistent_blocks(wb, resident_blocks);
     const uint32_t shade_blocks = (wb.segments + 3) / 4;
     hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
+    if (sc.textures) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
+    else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
     hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 
 int wavefront_finish(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t resident_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wf_finish, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    if (sc.textures) hipLaunchKernelGGL(k_wf_finish<true>, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    else hipLaunchKernelGGL(k_wf_finish<false>, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 

@@ -176,6 +176,17 @@ int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches);
 /* Standalone OpenEXR writer used by Film::SaveTo (src/pathtracer/film.cpp:61-68). */
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height);
 
+/* ---- material maps -----------------------------------------------------------------------------
+ * Replaces: LoadTexture (stb_image, 4 channels) + CuTexture      src/scene/loader.cpp:71-97,
+ *           src/cuda_helpers/texture.cpp:5-27; MaterialValue::At  src/kernels/material/common.cuh:15-27.
+ * Decodes a PNG or PPM/PGM file to RGBA8 (row 0 first, red in the low byte of each word).  With
+ * rgba == NULL only the size is returned; capacity is in pixels. */
+int cpt_image_load(const char *path, uint32_t *width, uint32_t *height, uint32_t *rgba, size_t capacity);
+int cpt_image_save_png(const char *path, const uint32_t *rgba, uint32_t width, uint32_t height);
+/* size of the map of mesh object `index`'s material: which = 0 diffuse, 1 specular, 2 emission;
+ * width = height = 0 when the material has no such map; rgba may be NULL */
+int cpt_scene_object_map(const cpt_scene *s, uint32_t index, int which, uint32_t *width, uint32_t *height, uint32_t *rgba, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

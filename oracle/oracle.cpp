@@ -20,7 +20,9 @@
 // NOT buildable here: for those two pieces parity is pinned only by the node arrays
 // and image statistics recorded from the reference during the survey
 // (tests/golden/cornell_lbvh.json) -- otherwise "parity unpinned".
+#include <array>
 #include <cmath>
+#include <memory>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
@@ -854,16 +856,64 @@ struct Bsdf {
     }
 };
 
+// ------------------------------------------------------------------ textures
+// RGBA8 sRGB image sampled the way the reference's texture objects are set up
+// (src/cuda_helpers/texture.cpp:5-27: normalised coordinates, wrap, linear filter, sRGB texels read
+// as normalised floats).  The reference leaves the arithmetic to the texture unit; this is the
+// fetch the CUDA programming guide describes for that mode: texel centres at (i + 0.5) / size,
+// bilinear weights with 8 fractional bits, sRGB decode per texel before the blend.  Not pinned by
+// anything the reference holds (no shipped scene has a map).
+struct Texture {
+    uint32_t width = 0, height = 0;
+    std::vector<uint32_t> rgba;
+};
+inline const float *SrgbToLinear() {
+    static const std::array<float, 256> lut = [] {
+        std::array<float, 256> t{};
+        for (int c = 0; c < 256; c++) {
+            const float s = (float)c / 255.0f;
+            t[c] = s <= 0.04045f ? s / 12.92f : std::pow((s + 0.055f) / 1.055f, 2.4f);
+        }
+        return t;
+    }();
+    return lut.data();
+}
+inline V3 Tex2D(const Texture &t, float u, float v) {
+    const float *lut = SrgbToLinear();
+    const float x = (u - std::floor(u)) * (float)t.width - 0.5f, y = (v - std::floor(v)) * (float)t.height - 0.5f;
+    const float fx = std::floor(x), fy = std::floor(y);
+    const float a = std::floor((x - fx) * 256.0f + 0.5f) * (1.0f / 256.0f), b = std::floor((y - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int w = (int)t.width, h = (int)t.height;
+    int x0 = (int)fx % w, y0 = (int)fy % h;
+    if (x0 < 0) x0 += w;
+    if (y0 < 0) y0 += h;
+    const int x1 = x0 + 1 == w ? 0 : x0 + 1, y1 = y0 + 1 == h ? 0 : y0 + 1;
+    const uint32_t t00 = t.rgba[y0 * w + x0], t10 = t.rgba[y0 * w + x1], t01 = t.rgba[y1 * w + x0], t11 = t.rgba[y1 * w + x1];
+    float out[3];
+    for (int k = 0; k < 3; k++) {
+        const int shift = 8 * k;
+        const float c00 = lut[(t00 >> shift) & 255u], c10 = lut[(t10 >> shift) & 255u], c01 = lut[(t01 >> shift) & 255u], c11 = lut[(t11 >> shift) & 255u];
+        out[k] = (1.0f - a) * (1.0f - b) * c00 + a * (1.0f - b) * c10 + (1.0f - a) * b * c01 + a * b * c11;
+    }
+    return V3{out[0], out[1], out[2]};
+}
+
 // ------------------------------------------------------------------ material (material/mtl.cuh, src/scene/material.hpp)
 struct Material {
     V3 emission{0, 0, 0}, diffuse{0.5f, 0.5f, 0.5f}, specular{0.5f, 0.5f, 0.5f}, transmittance{0, 0, 0};
     float shininess = 1.0f, ior = 1.5f, opacity = 1.0f;
     int bsdf_type = eBlinnPhong;
+    const Texture *emission_map = nullptr, *diffuse_map = nullptr, *specular_map = nullptr;   // src/scene/material.cpp:21-40
 
     bool IsEmissive() const { return dot(emission, emission) > 0.0f; }   // src/scene/material.cpp:57-59
 
-    // material/material.cuh:15-27 + material/mtl.cuh:16-66 (constant values only, no textures)
-    Bsdf GetBsdf() const {
+    // MaterialValue::At, material/common.cuh:15-27
+    static V3 At(V3 value, const Texture *map, V2 uv) { return map ? Tex2D(*map, uv.x, 1.0f - uv.y) : value; }
+    V3 EmissionAt(V2 uv) const { return At(emission, emission_map, uv); }
+
+    // material/material.cuh:15-27 + material/mtl.cuh:16-66
+    Bsdf GetBsdf(V2 uv = V2{0, 0}) const {
+        const V3 diffuse = At(this->diffuse, diffuse_map, uv), specular = At(this->specular, specular_map, uv), emission = EmissionAt(uv);
         Bsdf b;
         if (bsdf_type != eMicrofacet && opacity == 0.0f) {
             b.type = eGlass;
@@ -916,6 +966,7 @@ struct Scene {
     std::vector<Bbox> top_bboxes;
     std::vector<uint64_t> top_keys;
     std::vector<int> lights;     // instance index per light (pathtracer.cpp:187-200)
+    std::vector<std::unique_ptr<Texture>> textures;
     PinholeCamera camera{};
     bool has_camera = false;
     bool built = false;
@@ -989,7 +1040,7 @@ ShadingSurface GetShadingSurface(const Scene &sc, const HitInfo &hit) {
     v.normal = xyz(normalize4(mul(transform_it, V4{v.normal.x, v.normal.y, v.normal.z, 0.0f})));   // vec4 normalize, as written
     ShadingSurface s;
     s.vertex = v;
-    s.bsdf = inst.material.GetBsdf();
+    s.bsdf = inst.material.GetBsdf(v.texcoord);
     return s;
 }
 
@@ -1010,7 +1061,7 @@ LightSample GeometryLightSample(const Scene &sc, const Instance &inst, V3 pos, V
     samp.dist = dist;
     float cos_theta = dot(-dir, vert.normal);
     samp.pdf = cos_theta > 0.0f ? vert.pdf * dist_sqr / cos_theta : 0.0f;
-    samp.weight = inst.material.emission / samp.pdf;
+    samp.weight = inst.material.EmissionAt(vert.texcoord) / samp.pdf;
     return samp;
 }
 
@@ -1250,6 +1301,31 @@ void orc_trs_matrix(const float *t3, const float *r3, const float *s3, float *ou
     M4 inv = inverse(m);
     std::memcpy(out16, &m, 64);
     std::memcpy(out_inv16, &inv, 64);
+}
+
+// RGBA8 image (row 0 first, red in the low byte); returns its 1-based number
+int orc_scene_add_texture(void *h, uint32_t width, uint32_t height, const uint32_t *rgba) {
+    Scene &sc = *static_cast<Scene *>(h);
+    auto t = std::make_unique<Texture>();
+    t->width = width; t->height = height;
+    t->rgba.assign(rgba, rgba + (size_t)width * height);
+    sc.textures.push_back(std::move(t));
+    return (int)sc.textures.size();
+}
+// maps of an instance's material by texture number, 0 = none (diffuse, specular, emission)
+void orc_scene_set_maps(void *h, int instance, int diffuse, int specular, int emission) {
+    Scene &sc = *static_cast<Scene *>(h);
+    Material &m = sc.instances[instance].material;
+    m.diffuse_map = diffuse ? sc.textures[diffuse - 1].get() : nullptr;
+    m.specular_map = specular ? sc.textures[specular - 1].get() : nullptr;
+    m.emission_map = emission ? sc.textures[emission - 1].get() : nullptr;
+}
+void orc_tex2d(uint32_t width, uint32_t height, const uint32_t *rgba, float u, float v, float *out3) {
+    Texture t;
+    t.width = width; t.height = height;
+    t.rgba.assign(rgba, rgba + (size_t)width * height);
+    V3 c = Tex2D(t, u, v);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
 }
 
 // src/scene/camera.cpp:28-50

@@ -66,6 +66,10 @@ def oracle():
     L.orc_mesh_vertex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float, f32p]
     L.orc_frame.argtypes = [f32p, f32p]
     L.orc_trs_matrix.argtypes = [f32p, f32p, f32p, f32p, f32p]
+    u32arr = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    L.orc_scene_add_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32arr]
+    L.orc_scene_set_maps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_tex2d.argtypes = [C.c_uint32, C.c_uint32, u32arr, C.c_float, C.c_float, f32p]
     L.orc_luminance.restype = C.c_float
     L.orc_luminance.argtypes = [C.c_float, C.c_float, C.c_float]
     _oracle = L
@@ -293,7 +297,13 @@ class OracleScene:
         for o in objects:
             m = self.L.orc_scene_add_mesh(self.h, o["positions"], o["normals"], o["texcoords"], len(o["positions"]),
                                           o["indices"], len(o["indices"]) // 3)
-            self.L.orc_scene_add_instance(self.h, m, object_transform(o)[0], o["material"])
+            inst = self.L.orc_scene_add_instance(self.h, m, object_transform(o)[0], o["material"])
+            numbers = []
+            for key in ("map_Kd", "map_Ks", "map_Ke"):        # (h, w) uint32 RGBA8 arrays
+                img = o.get(key)
+                numbers.append(0 if img is None else self.L.orc_scene_add_texture(self.h, img.shape[1], img.shape[0], np.ascontiguousarray(img)))
+            if any(numbers):
+                self.L.orc_scene_set_maps(self.h, inst, *numbers)
         if camera is not None:
             self.L.orc_scene_set_camera(self.h, camera["pos"], camera["look_at"], camera["up"], camera["fov"])
         self.L.orc_scene_build(self.h)
@@ -343,6 +353,58 @@ class OracleScene:
 def cornell(glass=False, bsdf_type=2):
     d = os.path.join(SCENES, "cornell-box-glass" if glass else "cornell-box")
     return load_obj_scene(os.path.join(d, "cornell-box.obj"), bsdf_type), load_json_camera(os.path.join(d, "cornell-box.json"))
+
+
+def write_ppm(path, rgba):
+    """(h, w) uint32 RGBA8 -> binary PPM (alpha dropped)."""
+    h, w = rgba.shape
+    rgb = np.stack([(rgba >> s) & 255 for s in (0, 8, 16)], axis=-1).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(rgb.tobytes())
+
+
+def textured_box_files(directory, bsdf_names=("Kd", "Ks", "Ke")):
+    """A closed room with mapped materials, written as .obj/.mtl/.ppm: floor with a diffuse map,
+    back wall with diffuse + specular maps, ceiling lamp with an emission map (and a constant Ke,
+    which is what makes it a light), an untextured block.  Returns (obj path, camera dict, maps)
+    where maps[material name] = {"map_Kd": array, ...}."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    def image(w, h, lo, hi):
+        c = rng.integers(lo, hi, (h, w, 3), dtype=np.uint32)
+        yy, xx = np.mgrid[0:h, 0:w]
+        c[((xx // 3 + yy // 2) % 2) == 0] //= 3
+        return (c[..., 0] | (c[..., 1] << 8) | (c[..., 2] << 16) | (255 << 24)).astype(np.uint32)
+    maps = {"floor": {"map_Kd": image(16, 12, 40, 256)},
+            "wall": {"map_Kd": image(7, 5, 60, 230), "map_Ks": image(4, 4, 0, 90)},
+            "lamp": {"map_Ke": image(8, 8, 120, 256)}}
+    mtl = []
+    for name, consts in (("floor", "Kd 0.3 0.3 0.3\nKs 0 0 0"), ("wall", "Kd 0.5 0.5 0.5\nKs 0.2 0.2 0.2\nNs 20"),
+                         ("lamp", "Kd 0 0 0\nKs 0 0 0\nKe 9 9 9"), ("plain", "Kd 0.6 0.3 0.2\nKs 0.1 0.1 0.1\nNs 8")):
+        mtl.append("newmtl %s\n%s" % (name, consts))
+        for key, img in maps.get(name, {}).items():
+            fname = "%s_%s.ppm" % (name, key)
+            write_ppm(os.path.join(directory, fname), img)
+            mtl.append("%s %s" % (key, fname))
+        mtl.append("")
+    open(os.path.join(directory, "room.mtl"), "w").write("\n".join(mtl))
+    def quad(name, mat, p, n, uvscale=1.0):
+        return ["o %s" % name, "usemtl %s" % mat] + ["v %g %g %g" % tuple(q) for q in p] + \
+               ["vt %g %g" % (u * uvscale, v * uvscale) for u, v in ((0, 0), (1, 0), (1, 1), (0, 1))] + ["vn %g %g %g" % tuple(n)] * 4 + \
+               ["f -4/-4/-4 -3/-3/-3 -2/-2/-2", "f -4/-4/-4 -2/-2/-2 -1/-1/-1"]
+    lines = ["mtllib room.mtl"]
+    lines += quad("floor", "floor", [(-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)], (0, 1, 0), 2.5)      # uv beyond [0,1]: wrap
+    lines += quad("back", "wall", [(-1, 0, 1), (1, 0, 1), (1, 2, 1), (-1, 2, 1)], (0, 0, -1))
+    lines += quad("left", "plain", [(-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1)], (1, 0, 0))
+    lines += quad("right", "plain", [(1, 0, 1), (1, 0, -1), (1, 2, -1), (1, 2, 1)], (-1, 0, 0))
+    lines += quad("ceiling", "plain", [(-1, 2, 1), (1, 2, 1), (1, 2, -1), (-1, 2, -1)], (0, -1, 0))
+    lines += quad("lamp", "lamp", [(-0.4, 1.98, 0.4), (0.4, 1.98, 0.4), (0.4, 1.98, -0.4), (-0.4, 1.98, -0.4)], (0, -1, 0))
+    lines += quad("block", "plain", [(-0.5, 0.4, 0.2), (0.3, 0.4, 0.0), (0.4, 0.4, 0.6), (-0.3, 0.4, 0.7)], (0, 1, 0))
+    obj = os.path.join(directory, "room.obj")
+    open(obj, "w").write("\n".join(lines) + "\n")
+    cam = dict(pos=np.array([0.0, 1.0, -2.6], np.float32), look_at=np.array([0.0, 0.9, 0.0], np.float32),
+               up=np.array([0, 1, 0], np.float32), fov=45.0, width=64, height=64)
+    return obj, cam, maps
 
 
 # --------------------------------------------------------------------------- synthetic scenes

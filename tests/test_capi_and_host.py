@@ -129,6 +129,127 @@ def test_number_grammar_of_the_reference_reader(cpt, tmp_path):
     assert np.array_equal(o["positions"], want), o["positions"]
 
 
+def _png(path, width, height, color, depth, rows, palette=None, trns=None, filters=None):
+    import zlib
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xffffffff)
+    raw = bytearray()
+    bpp = max(1, {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color] * depth // 8)
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        f = filters[y % len(filters)] if filters else 0
+        out = bytearray(len(row))
+        for i, x in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 0: pred = 0
+            elif f == 1: pred = a
+            elif f == 2: pred = b
+            elif f == 3: pred = (a + b) // 2
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+            out[i] = (x - pred) & 255
+        raw += bytes([f]) + out
+        prev = row
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, color, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    z = zlib.compress(bytes(raw))
+    data += chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(data)
+
+
+def test_image_readers(cpt, tmp_path):
+    """PNG (every colour type, sub-byte depths, all five filters, split IDAT) and PPM/PGM against
+    pixel arrays built in the test; the PNG writer round-trips."""
+    rng = np.random.Generator(np.random.PCG64(4))
+    w, h = 13, 9
+    pack = lambda r, g, b, a: (r.astype(np.uint32) | (g.astype(np.uint32) << 8) | (b.astype(np.uint32) << 16) | (a.astype(np.uint32) << 24))
+    full = np.full((h, w), 255, np.uint32)
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    _png(tmp_path / "rgba.png", w, h, 6, 8, [rgba[y].tobytes() for y in range(h)], filters=[0, 1, 2, 3, 4])
+    assert np.array_equal(cpt.load_image(tmp_path / "rgba.png"), pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], rgba[..., 3]))
+    _png(tmp_path / "rgb.png", w, h, 2, 8, [rgba[y, :, :3].tobytes() for y in range(h)], filters=[4, 3])
+    assert np.array_equal(cpt.load_image(tmp_path / "rgb.png"), pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], full))
+    _png(tmp_path / "ga.png", w, h, 4, 8, [rgba[y, :, :2].tobytes() for y in range(h)], filters=[1])
+    assert np.array_equal(cpt.load_image(tmp_path / "ga.png"), pack(rgba[..., 0], rgba[..., 0], rgba[..., 0], rgba[..., 1]))
+    rgb16 = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+    _png(tmp_path / "rgb16.png", w, h, 2, 16, [rgb16[y].astype(">u2").tobytes() for y in range(h)], filters=[2])
+    hi = (rgb16 >> 8).astype(np.uint32)
+    assert np.array_equal(cpt.load_image(tmp_path / "rgb16.png"), pack(hi[..., 0], hi[..., 1], hi[..., 2], full))
+    idx = rng.integers(0, 4, (h, w), dtype=np.uint8)          # 2-bit palette with transparency
+    rows = []
+    for y in range(h):
+        bits = np.zeros(((w * 2 + 7) // 8) * 4, np.uint8)
+        bits[:w] = idx[y]
+        rows.append(bytes(int(bits[4 * k] << 6 | bits[4 * k + 1] << 4 | bits[4 * k + 2] << 2 | bits[4 * k + 3]) for k in range(len(bits) // 4)))
+    pal = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]], np.uint8)
+    _png(tmp_path / "pal.png", w, h, 3, 2, rows, palette=pal.reshape(-1), trns=[255, 128])
+    alpha = np.array([255, 128, 255, 255], np.uint32)[idx]
+    assert np.array_equal(cpt.load_image(tmp_path / "pal.png"), pack(pal[idx][..., 0], pal[idx][..., 1], pal[idx][..., 2], alpha))
+    g4 = rng.integers(0, 16, (h, w), dtype=np.uint8)          # 4-bit grey
+    rows = [bytes(int((np.append(g4[y], 0)[2 * k] << 4) | np.append(g4[y], 0)[2 * k + 1]) for k in range((w + 1) // 2)) for y in range(h)]
+    _png(tmp_path / "g4.png", w, h, 0, 4, rows)
+    g8 = (g4.astype(np.uint32) * 255) // 15
+    assert np.array_equal(cpt.load_image(tmp_path / "g4.png"), pack(g8, g8, g8, full))
+    write_ppm(tmp_path / "a.ppm", pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], full))
+    assert np.array_equal(cpt.load_image(tmp_path / "a.ppm"), pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], full))
+    (tmp_path / "t.pgm").write_text("P2\n# comment\n3 2\n15\n0 5 15\n1 2 3\n")
+    g = (np.array([[0, 5, 15], [1, 2, 3]], np.uint32) * 255 + 7) // 15
+    assert np.array_equal(cpt.load_image(tmp_path / "t.pgm"), pack(g, g, g, np.full((2, 3), 255, np.uint32)))
+    cpt.save_png(tmp_path / "round.png", pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], rgba[..., 3]))
+    assert np.array_equal(cpt.load_image(tmp_path / "round.png"), pack(rgba[..., 0], rgba[..., 1], rgba[..., 2], rgba[..., 3]))
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 20)
+    with pytest.raises(cpt.CptError):
+        cpt.load_image(tmp_path / "bad.png")
+    with pytest.raises(cpt.CptError):
+        cpt.load_image(tmp_path / "missing.png")
+
+
+def test_material_maps_are_loaded_with_the_scene(cpt, tmp_path):
+    obj, cam, maps = textured_box_files(str(tmp_path))
+    sc = cpt.Scene().load_obj(obj, 2)
+    names = [o["name"] for o in sc.objects()]
+    for i, name in enumerate(names):
+        mat = name.split("-")[-1]
+        for which, key in enumerate(("map_Kd", "map_Ks", "map_Ke")):
+            got = sc.object_map(i, which)
+            want = maps.get(mat, {}).get(key)
+            assert (got is None) == (want is None), (name, key)
+            if want is not None:
+                assert np.array_equal(got, want), (name, key)
+    (tmp_path / "broken.mtl").write_text("newmtl m\nKd 0.25 0.5 0.75\nmap_Kd nothing.png\n")
+    (tmp_path / "broken.obj").write_text("mtllib broken.mtl\nusemtl m\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n")
+    sc = cpt.Scene().load_obj(str(tmp_path / "broken.obj"), 2)     # a map that cannot be read leaves the constant
+    assert sc.object_map(0, 0) is None and np.array_equal(sc.object(0)["material"][3:6], np.float32([0.25, 0.5, 0.75]))
+
+
+def test_texture_fetch_of_the_oracle():
+    """tex2D as the CUDA programming guide describes it for normalised, wrapped, linearly filtered,
+    sRGB textures: texel centres, wrap-around neighbours, 8-bit blend weights."""
+    L = oracle()
+    img = np.array([[0x000000ff, 0x0000ff00], [0x00ff0000, 0x00ffffff]], np.uint32)       # red green / blue white
+    out = np.zeros(3, np.float32)
+    L.orc_tex2d(2, 2, img, 0.25, 0.25, out)
+    assert np.array_equal(out, [1, 0, 0])                       # centre of texel (0, 0)
+    L.orc_tex2d(2, 2, img, 0.75, 0.75, out)
+    assert np.array_equal(out, [1, 1, 1])
+    L.orc_tex2d(2, 2, img, 0.5, 0.25, out)                      # half way between red and green
+    assert np.array_equal(out, [0.5, 0.5, 0])
+    L.orc_tex2d(2, 2, img, 0.0, 0.25, out)                      # left edge blends with the wrapped right neighbour
+    assert np.array_equal(out, [0.5, 0.5, 0])
+    L.orc_tex2d(2, 2, img, 1.25, -0.75, out)                    # wrap in both directions
+    assert np.array_equal(out, [1, 0, 0])
+    grey = np.array([[0xff7f7f7f]], np.uint32)
+    L.orc_tex2d(1, 1, grey, 0.3, 0.9, out)
+    assert abs(out[0] - 0.2122) < 1e-3 and out[0] == out[1] == out[2]     # sRGB 127 -> linear
+
+
 def test_bsdf_type_flag_and_default_material(cpt, tmp_path):
     obj = tmp_path / "t.obj"
     obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 3/1/1 4/1/1\n")

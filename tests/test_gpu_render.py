@@ -67,6 +67,35 @@ def test_transformed_instances_render(cpt):
     assert np.abs(nrm[..., :3] - ref_n[..., :3]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("bsdf", [2, 0, 3])
+def test_material_maps_render_like_the_oracle(cpt, tmp_path, bsdf):
+    """Diffuse, specular and emission maps (MaterialValue::At, material/common.cuh:15-27): texture
+    coordinates beyond [0, 1], the lamp's emission read at the sampled point and at the hit.  The
+    oracle's fetch is a restatement of the documented CUDA filtering, not of anything in the reference."""
+    obj, cam, maps = textured_box_files(str(tmp_path))
+    objs = load_obj_scene(obj, bsdf)
+    for o in objs:
+        o.update(maps.get(o["name"].split("-")[-1], {}))
+    osc = OracleScene(objs, cam)
+    sc = cpt.Scene().load_obj(obj, bsdf)
+    sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], 64, 64)
+    imgs = []
+    for mode in (0, 1, 2):
+        tr = cpt.Tracer(sc, 64, 64, max_depth=5).build_buffers()
+        tr.set_integrator(mode)
+        tr.update(16)
+        imgs.append(tr.film())
+    ref, _ = osc.render(64, 64, 1, 17, 5)
+    compare(imgs[0], ref)
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32)) and np.array_equal(imgs[0].view(np.uint32), imgs[2].view(np.uint32))
+    plain = [dict(o) for o in objs]
+    for o in plain:
+        for k in ("map_Kd", "map_Ks", "map_Ke"):
+            o.pop(k, None)
+    flat, _ = OracleScene(plain, cam).render(64, 64, 1, 17, 5)
+    assert np.linalg.norm(flat[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3]) > 0.1      # the maps matter in this scene
+
+
 def test_survey_statistics(cpt):
     d = os.path.join(SCENES, "cornell-box-glass")
     sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
