@@ -10,6 +10,9 @@ is one launch of the bounce-loop megakernel over every pixel.  With N > 1 every 
 block of K sample indices into a sum buffer (weak scaling, no data-path collective) and the timed
 region ends with one sum-reduce of the 16.8 MB buffers to rank 0 (RCCL through torch.distributed).
 
+--workload heightfield-10m (etc.) renders a synthetic scene of the named size instead (BASELINE.json
+configs 3-5), --integrator picks the bounce-loop variant; the defaults are the metric's configuration.
+
 Prints ONE JSON line on rank 0.  Scene data comes from tests/golden/scenes (data fixtures);
 nothing outside this repository is read.  The oracle (oracle/) is used only for the `cpu_baseline`
 leg, never for the measured path.
@@ -101,6 +104,9 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--max-depth", type=int, default=8)
+    ap.add_argument("--workload", default="cornell-box-glass",
+                    help="cornell-box-glass (the metric's configuration, default) or a synthetic scene: heightfield-1m, heightfield-10m, soup-1m, soup-10m")
+    ap.add_argument("--integrator", type=int, default=0, help="0 persistent megakernel (default), 1 megakernel, 2 wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -128,9 +134,27 @@ def main():
     cpt.check(cpt.lib.cpt_set_device(local_rank))
     W, H, K, WU = args.width, args.height, args.steps, args.warmup
 
-    d = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box-glass")
-    scene = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
-    tracer = cpt.Tracer(scene, W, H, max_depth=args.max_depth).build_buffers()
+    if args.workload == "cornell-box-glass":
+        d = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box-glass")
+        scene = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+        workload = f"cornell-box-glass {W}x{H}, max-depth {args.max_depth}, glass box"
+    else:
+        from helpers import synthetic_scene
+        kind, _, size = args.workload.partition("-")
+        ntris = {"1m": 1_000_000, "10m": 10_000_000}.get(size)
+        if kind not in ("heightfield", "soup") or ntris is None:
+            raise SystemExit(f"unknown workload {args.workload}")
+        objs, cam = synthetic_scene(kind, ntris)            # seeded generator: every rank builds the same scene
+        scene = cpt.Scene()
+        for o in objs:
+            scene.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+        scene.set_camera([0.5, 0.3, 0.1], [0.5, 0.0, 0.45], [0, 1, 0], 40.0, W, H)
+        workload = f"synthetic {kind}, {len(objs[0]['indices']) // 3} triangles + emissive quad, {W}x{H}, max-depth {args.max_depth}"
+    tracer = cpt.Tracer(scene, W, H, max_depth=args.max_depth)
+    tracer.set_integrator(args.integrator)
+    tracer.build_buffers()
+    kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish"}[args.integrator]
+    integrator_name = {0: "persistent megakernel (lane regeneration)", 1: "megakernel, one lane per pixel", 2: "wavefront (ray queues) + persistent tail"}[args.integrator]
 
     def barrier():
         if world > 1:
@@ -189,7 +213,8 @@ def main():
     if rank == 0:
         paths = W * H * K * world
         result = {
-            "metric": "Mpaths/s per node, cornell-box-glass 1024x1024 max-depth 8 (Mrays/s and LBVH build ms @1M/10M alongside)",
+            "metric": "Mpaths/s per node, cornell-box-glass 1024x1024 max-depth 8 (Mrays/s and LBVH build ms @1M/10M alongside)"
+                      if args.workload == "cornell-box-glass" else f"Mpaths/s per node, {args.workload}",
             "value": round(paths / elapsed / 1e6, 3),
             "unit": "Mpaths/s",
             "n_gpus": world,
@@ -200,9 +225,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "reference scene file cornell-box-glass (committed fixture); synthetic soups for the LBVH timings",
-            "config": {"workload": f"cornell-box-glass {W}x{H}, max-depth {args.max_depth}, glass box, 1 spp per step, {K} spp per GPU",
-                       "integrator": "persistent megakernel (lane regeneration)", "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks + 1 sum-reduce"},
+            "data": "reference scene file cornell-box-glass (committed fixture); synthetic soups for the LBVH timings"
+                    if args.workload == "cornell-box-glass" else "synthetic scene from a seeded generator (tests/helpers.py); synthetic soups for the LBVH timings",
+            "config": {"workload": f"{workload}, 1 spp per step, {K} spp per GPU",
+                       "integrator": integrator_name, "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks + 1 sum-reduce"},
             "mrays_per_s": round(total["rays"] / elapsed / 1e6, 3),
             "rays_per_path": round(total["rays"] / max(total["paths"], 1), 4),
         }
@@ -212,17 +238,17 @@ def main():
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.workload == "cornell-box-glass" and args.integrator == 0 and (W, H, args.max_depth) == (1024, 1024, 8):
                 try:
                     traffic = json.load(open(tpath)).get("k_render_regen_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            result["roofline"] = {"kernel": "k_render_regen", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            result["roofline"] = {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         if world == 1 and not args.no_lbvh:
             result["lbvh"] = {"1M": lbvh_timings(cpt, 1_000_000), "10M": lbvh_timings(cpt, 10_000_000)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cornell-box-glass":
             result["cpu_baseline"] = cpu_baseline(W, H, args.max_depth)
         print(json.dumps(result), flush=True)
 
