@@ -133,6 +133,12 @@ int cpt_builder_set_sort(cpt_builder *b, int variant) {
     return CPT_OK;
 }
 
+int cpt_builder_set_carrier_limit(cpt_builder *b, uint32_t limit) {
+    if (!b) return Fail(CPT_ERR_INVALID, "cpt_builder_set_carrier_limit: null builder");
+    b->ws.carrier_limit = limit;
+    return CPT_OK;
+}
+
 int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
                       uint32_t num_primitives, float *elapsed_ms, float *stage_ms) {
     if (!b || !d_nodes || !d_bboxes || !merged_bbox) return Fail(CPT_ERR_INVALID, "cpt_builder_build: null argument");

@@ -13,6 +13,9 @@ struct BuildWorkspace {
     // radix sort variant: 0 = tile histograms + scan + scatter per pass (default, faster on this part),
     // 1 = onesweep (histograms with the keys, one look-back kernel per pass)
     int sort_variant = 0;
+    // nodes per workgroup of the first hierarchy pass that may be handed to the second pass (at most 64, the
+    // default); the rest climbs inside the first pass.  Lower values exist to exercise that path in tests.
+    uint32_t carrier_limit = 64;
     static size_t bytes_for(uint32_t num_primitives);
     int reserve(uint32_t num_primitives);
     void release();

@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) k_climb(const Carrier *__restrict__ ca
 
 template <bool PARENTS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__ keys, const Bbox *__restrict__ leaf_src, Bbox *bboxes, AccelNode *nodes,
-                                                    uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, Bbox merged, uint32_t n) {
+                                                    uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, uint32_t carrier_limit, Bbox merged, uint32_t n) {
     __shared__ Carrier s_park[kCarriersPerGroup];
     __shared__ uint32_t s_park_count;
     __shared__ uint64_t s_key[BLOCK + 2];        // keys b0-1 .. b1+1
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
             // so that the memory round trips of that exchange do not stall the lanes of this wave
             // that still work in LDS.
             const uint32_t slot = atomicAdd(&s_park_count, 1u);
-            if (slot < kCarriersPerGroup) {
+            if (slot < carrier_limit) {
                 s_park[slot] = Carrier{l, r, idx, 0u};
             } else {                                      // no room: climb from here, through memory
                 float lw = merged.pmax.w, hw = merged.pmin.w;
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
         internal = true;
     }
     __syncthreads();
-    const uint32_t parked = min(s_park_count, kCarriersPerGroup);
+    const uint32_t parked = min(s_park_count, carrier_limit);
     if (t < parked) carriers[(size_t)blockIdx.x * kCarriersPerGroup + t] = s_park[t];
     if (t == 0) carrier_counts[blockIdx.x] = parked;
 }
@@ -892,16 +892,17 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     mark(2);
     if (n > 1) {
         const uint32_t groups = cdiv(n, kUpBlock);
+        const uint32_t carrier_limit = ws->carrier_limit < kCarriersPerGroup ? ws->carrier_limit : kCarriersPerGroup;
         HIP_OK(hipMemsetAsync(slots, 0, 4 * (size_t)(n - 1), stream));      // one exchange word per split
         if (parents_out) {
             hipLaunchKernelGGL((k_build_up<true, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers,
-                               carrier_counts, merged, n);
+                               carrier_counts, carrier_limit, merged, n);
             mark(3);
             hipLaunchKernelGGL(k_climb<true>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, parents_out, slots, merged, n);
         } else {
             hipLaunchKernelGGL((k_build_up<false, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, (uint32_t *)nullptr, slots,
-                               carriers, carrier_counts, merged, n);
+                               carriers, carrier_counts, carrier_limit, merged, n);
             mark(3);
             hipLaunchKernelGGL(k_climb<false>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, (uint32_t *)nullptr, slots, merged, n);

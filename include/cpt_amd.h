@@ -71,6 +71,10 @@ void cpt_builder_destroy(cpt_builder *b);
  * 1 = onesweep: digit histograms computed with the keys, one kernel per pass with decoupled look-back.
  * Same result; on MI355X variant 0 is the faster one (look-back steps cross the per-XCD L2s). */
 int cpt_builder_set_sort(cpt_builder *b, int variant);
+/* How many nodes per workgroup the first hierarchy pass may hand to the second one (default and maximum 64);
+ * the others finish their climb inside the first pass.  Same result for every value; smaller values are for
+ * testing that path. */
+int cpt_builder_set_carrier_limit(cpt_builder *b, uint32_t limit);
 int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8],
                       uint32_t num_primitives, float *elapsed_ms, float *stage_ms);
 

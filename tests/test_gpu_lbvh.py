@@ -149,6 +149,27 @@ def test_onesweep_sort_variant_gives_the_same_tree(cpt, n):
     assert np.array_equal(d_boxes.to_host().view(np.uint32), o_boxes.view(np.uint32))
 
 
+@pytest.mark.parametrize("limit", [0, 1, 5])
+def test_hierarchy_nodes_that_do_not_fit_the_second_pass_climb_in_place(cpt, limit):
+    """With the hand-over list of the first hierarchy pass cut short, most nodes that span workgroups take
+    the in-kernel climb through memory, and mix with the ones that were handed over."""
+    for n, kind in ((100000, "soup"), (70000, "heightfield")):
+        soup = random_soup(n, seed=31) if kind == "soup" else heightfield(int((n / 2) ** 0.5), int((n / 2) ** 0.5), 3)
+        boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+        n = len(boxes)
+        d_leaf = cpt.DeviceArray.from_host(boxes)
+        d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
+        d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
+        b = cpt.lib.cpt_builder_create()
+        cpt.check(cpt.lib.cpt_builder_set_carrier_limit(b, limit))
+        ms = np.zeros(1, np.float32)
+        cpt.check(cpt.lib.cpt_builder_build(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, ms.ctypes.data, None))
+        cpt.lib.cpt_builder_destroy(b)
+        o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
+        assert np.array_equal(d_nodes.to_host(), o_nodes)
+        assert np.array_equal(d_boxes.to_host().view(np.uint32), o_boxes.view(np.uint32))
+
+
 def test_reusable_builder_is_deterministic(cpt):
     soup = random_soup(200000, seed=77)
     boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
