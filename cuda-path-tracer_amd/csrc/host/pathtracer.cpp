@@ -44,6 +44,11 @@ void PathTracer::BuildBuffers() {
     });
 
     BuildInstancesAndLights();
+    // about 7 MB of node and triangle records: beyond that the BVH no longer lives in the caches next to the CUs
+    size_t triangles = 0;
+    scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { triangles += mesh.GetMesh()->IndicesCount() / 3; });
+    const bool dense = triangles >= 65536;
+    if (dense != wf_dense_) { wf_dense_ = dense; wf_.capacity = 0; }      // the resident workgroup count is looked up again
     CPT_HIP(hipStreamSynchronize(stream_));
     built_ = true;
 }
@@ -280,7 +285,7 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
         wf_.segments = (uint32_t)segments;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        wf_resident_blocks_ = cpt::wavefront_resident_blocks(device);
+        wf_resident_blocks_ = cpt::wavefront_resident_blocks(device, wf_dense_);
         wf_finish_blocks_ = cpt::wavefront_finish_resident_blocks(device);
     }
     const uint32_t resident = (uint32_t)wf_resident_blocks_;
@@ -292,7 +297,7 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     uint32_t queued = needed;
     if (!pure && (uint32_t)wavefront_tail_ < queued) queued = (uint32_t)wavefront_tail_;
     if (queued != 0xffffffffu) {
-        for (uint32_t b = 0; b < queued; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b + 1, resident, stream_), "wavefront bounce");
+        for (uint32_t b = 0; b < queued; b++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, b + 1, resident, wf_dense_, stream_), "wavefront bounce");
         if (queued < needed) rc_check(cpt::wavefront_finish(scene_dev_, p, wf_, (uint32_t)wf_finish_blocks_, stream_), "wavefront finish");
         return;
     }
@@ -300,7 +305,7 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     // bounce number while any path goes on, read it back after each group of bounces
     uint32_t bounce = 0, group = 4;
     for (;;) {
-        for (uint32_t k = 0; k < group; k++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, ++bounce, resident, stream_), "wavefront bounce");
+        for (uint32_t k = 0; k < group; k++) rc_check(cpt::wavefront_bounce(scene_dev_, p, wf_, ++bounce, resident, wf_dense_, stream_), "wavefront bounce");
         uint32_t marker = 0;
         CPT_HIP(hipMemcpyAsync(&marker, wf_.control + cpt::kControlLiveMarker, sizeof(marker), hipMemcpyDeviceToHost, stream_));
         CPT_HIP(hipStreamSynchronize(stream_));
@@ -318,15 +323,16 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
         return;
     }
-    if (!queue_.Size()) {
+    if (!queue_.Size() || resident_dense_ != wf_dense_) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_);
+        resident_dense_ = wf_dense_;
     }
-    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, stream_), "render");
+    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, stream_), "render");
     queue_parity_ ^= 1u;
 }
 

@@ -19,8 +19,8 @@ struct PathLane {
 // One trip for the whole wave: closest-hit trace for every live lane (camera rays and bounce rays
 // mixed), shading + light sampling, any-hit trace for the lanes with a shadow ray, BSDF sampling,
 // film write for the lanes whose path ended.  Every lane of the wave must call it.
-template <bool MAPS>
-__device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, PathLane &l, TraceStack &st, LaneCounters &cnt) {
+template <bool MAPS, class Stack>
+__device__ inline void path_trip(const SceneDev &sc, const RenderParams &p, PathLane &l, Stack &st, LaneCounters &cnt) {
     // ---- extend
     Hit hit;
     float tmax = kRayTMax;

@@ -114,11 +114,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
 // out one 8x8 tile at a time (SegmentFetch: a cursor per XCD over a contiguous band of tiles, so
 // neighbouring tiles share an L2); idle lanes are found with a ballot and numbered with a popcount
 // prefix.  One trip of the loop is path_trip().
-template <bool MAPS>
-__global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
-    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+// DENSE: the build for scenes whose BVH misses the vector L1: 5 waves per SIMD and 12 LDS stack entries
+// instead of 4 and 16 (a few registers spill, the extra wave hides more than that costs: heightfield 10M
+// 187 -> 199 Mpaths/s; cornell-box-glass, all L1 hits, is 10 % slower that way and keeps the other build).
+template <bool DENSE> struct RegenShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 12 : 16; };
+
+template <bool MAPS, bool DENSE>
+__global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
+    __shared__ uint2 s_stack[RegenShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
+    TraceStackT<RegenShape<DENSE>::kLdsEntries> st;
     st.lds = s_stack;
     LaneCounters cnt;
     uint32_t paths = 0;
@@ -159,11 +164,16 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_render_regen(SceneDev sc, Re
     flush_counters(sc, cnt, paths, s_cnt);
 }
 
-__global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
+// The batch query kernels hold one ray and no path state: few registers, so more waves per SIMD when
+// the LDS stack is shortened to match (deeper entries go to private memory).
+constexpr int kQueryWaves = 8;
+constexpr int kQueryLdsEntries = 8;
+
+__global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
-    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
+    TraceStackT<kQueryLdsEntries> st;
     st.lds = s_stack;
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
@@ -181,10 +191,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_first_hit(SceneDev sc, const fl
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
-__global__ void __launch_bounds__(kTraceBlock) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
-    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+__global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
+    __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
+    TraceStackT<kQueryLdsEntries> st;
     st.lds = s_stack;
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
@@ -265,19 +275,29 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
-int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, hipStream_t stream) {
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, hipStream_t stream) {
     uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
     if (tiles == 0) return 0;
     uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? want : max_blocks;
-    if (sc.textures) hipLaunchKernelGGL(k_render_regen<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
-    else hipLaunchKernelGGL(k_render_regen<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
+    const dim3 grid(blocks), block(kTraceBlock);
+    if (sc.textures) {
+        if (dense) hipLaunchKernelGGL((k_render_regen<true, true>), grid, block, 0, stream, sc, p, queue, parity);
+        else hipLaunchKernelGGL((k_render_regen<true, false>), grid, block, 0, stream, sc, p, queue, parity);
+    } else {
+        if (dense) hipLaunchKernelGGL((k_render_regen<false, true>), grid, block, 0, stream, sc, p, queue, parity);
+        else hipLaunchKernelGGL((k_render_regen<false, false>), grid, block, 0, stream, sc, p, queue, parity);
+    }
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_regen<true>, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+int render_regen_resident_blocks(int device, bool dense) {
+    int per_cu = 0, other = 0, cus = 0;
+    const void *with_maps = dense ? (const void *)k_render_regen<true, true> : (const void *)k_render_regen<true, false>;
+    const void *without = dense ? (const void *)k_render_regen<false, true> : (const void *)k_render_regen<false, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_maps, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, without, kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
+    if (other < per_cu) per_cu = other;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return per_cu * cus;
 }

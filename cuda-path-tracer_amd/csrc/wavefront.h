@@ -35,14 +35,17 @@ struct WavefrontBuffers {
 };
 
 size_t wavefront_slots(uint32_t width, uint32_t height);
-int wavefront_resident_blocks(int device);          // workgroups of a queue traversal kernel the device holds at once
+// workgroups of a queue traversal kernel the device holds at once; dense = the build with more waves per
+// SIMD and a shorter LDS stack, meant for scenes whose BVH does not fit the vector L1
+int wavefront_resident_blocks(int device, bool dense);
 int wavefront_finish_resident_blocks(int device);   // same for the finishing kernel
 // camera rays + fresh path state for sample p.spp; fills the queue
 int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, hipStream_t stream);
 // one bounce: extend the queued rays, shade (refills the queue and the shadow queue), trace shadow
 // rays.  `bounce_id` (non-zero, different for every bounce of a sample) is stored to the live
 // marker when at least one path goes on.
-int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t bounce_id, uint32_t resident_blocks, hipStream_t stream);
+int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t bounce_id, uint32_t resident_blocks, bool dense,
+                     hipStream_t stream);
 // runs every path still queued to its end in registers (one persistent launch)
 int wavefront_finish(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t resident_blocks, hipStream_t stream);
 

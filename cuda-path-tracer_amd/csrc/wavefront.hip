@@ -24,12 +24,12 @@ constexpr uint32_t kPrimaryBit = 0x80000000u;
 constexpr uint32_t kSpecularBit = 0x40000000u;
 constexpr uint32_t kPixelMask = 0x3fffffffu;
 constexpr int kRefillIdleLanes = 16;       // refill as soon as this many lanes of a wave are idle
-// Waves per SIMD and LDS stack entries per lane of the queue traversal kernels.  They keep no path
-// state in registers and would fit 6 waves per SIMD with 12 entries (24 KB per workgroup), but
-// measured on cornell-box-glass that is slower (311 vs ~200 us per closest-hit pass over 1M rays):
-// the traversal is not limited by latency that more resident waves could hide.
-constexpr int kQueueTraceWaves = 4;
-constexpr int kQueueTraceLdsEntries = 16;
+// Waves per SIMD and LDS stack entries per lane of the queue traversal kernels, two builds.  They
+// keep no path state in registers and fit 6 waves per SIMD with 12 entries (24 KB per workgroup).
+// On scenes whose BVH misses the vector L1 the extra waves hide the misses (heightfield 10M:
+// 229 -> 259 Mpaths/s); on cornell-box-glass, where every node is an L1 hit, they only add
+// contention (3.8 -> 5.4 ms per sample), so small scenes keep 4 waves and 16 entries.
+template <bool DENSE> struct QueueTraceShape { static constexpr int kWaves = DENSE ? 6 : 4, kLdsEntries = DENSE ? 12 : 16; };
 
 // one lane per pixel slot (8x8 tiles): camera ray + fresh path state, src/kernels/integrator/path.cu:86-96
 __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
@@ -57,11 +57,11 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
 // ray, result to wb.hit.  ANY = true: the path's shadow ray; an unoccluded ray adds the pending
 // light contribution to the path's colour, and a path that was only waiting for this ray is
 // written to the film.
-template <bool ANY>
-__global__ void __launch_bounds__(kTraceBlock, kQueueTraceWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
-    __shared__ uint2 s_stack[kQueueTraceLdsEntries * kTraceBlock];
+template <bool ANY, bool DENSE>
+__global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+    __shared__ uint2 s_stack[QueueTraceShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStackT<kQueueTraceLdsEntries> st;
+    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries> st;
     st.lds = s_stack;
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
@@ -289,9 +289,10 @@ static int resident_blocks_of(const void *const *kernels, int count, int device)
     return best * cus;
 }
 
-int wavefront_resident_blocks(int device) {
-    const void *kernels[2] = {(const void *)k_wf_trace<false>, (const void *)k_wf_trace<true>};
-    return resident_blocks_of(kernels, 2, device);
+int wavefront_resident_blocks(int device, bool dense) {
+    const void *sparse_kernels[2] = {(const void *)k_wf_trace<false, false>, (const void *)k_wf_trace<true, false>};
+    const void *dense_kernels[2] = {(const void *)k_wf_trace<false, true>, (const void *)k_wf_trace<true, true>};
+    return resident_blocks_of(dense ? dense_kernels : sparse_kernels, 2, device);
 }
 
 int wavefront_finish_resident_blocks(int device) {
@@ -313,13 +314,16 @@ int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const Wave
     return (int)hipGetLastError();
 }
 
-int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t bounce_id, uint32_t resident_blocks, hipStream_t stream) {
+int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t bounce_id, uint32_t resident_blocks, bool dense,
+                     hipStream_t stream) {
     const uint32_t blocks = persistent_blocks(wb, resident_blocks);
     const uint32_t shade_blocks = (wb.segments + 3) / 4;
-    hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    if (dense) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     if (sc.textures) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
     else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
-    hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    if (dense) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 
