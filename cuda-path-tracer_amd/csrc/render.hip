@@ -88,8 +88,8 @@ template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParams p) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStack st(s_stack, spill_entries);
     LaneCounters cnt;
     const uint32_t tiles_x = (p.width + 15) / 16;
     const uint32_t tile = xcd_band_remap(blockIdx.x, gridDim.x);
@@ -123,8 +123,8 @@ template <bool MAPS, bool DENSE>
 __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[RegenShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStackT<RegenShape<DENSE>::kLdsEntries> st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<RegenShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStackT<kQueryLdsEntries> st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<kQueryLdsEntries> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStackT<kQueryLdsEntries> st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<kQueryLdsEntries> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {

@@ -26,22 +26,37 @@ struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; };
 
 // Per-lane stack of (node reference, entry distance) pairs.  Entry e of lane l lives at
 // lds[e * 256 + l]: lanes of a wave always touch consecutive 8-byte slots, whatever their depths.
+// Pointers with their address space in the type: an access through a generic pointer is a FLAT
+// instruction, which has to find out at run time whether the address is LDS, private or global
+// memory and counts against both the memory and the LDS wait counters.  BVH records are always
+// global memory and the stack window is always LDS, so the hot loop says so.
+typedef float RawF4 __attribute__((ext_vector_type(4)));        // plain vectors: the HIP float4 / uint2 classes only bind generic references
+typedef uint32_t RawU2 __attribute__((ext_vector_type(2)));
+typedef const RawF4 __attribute__((address_space(1))) *GlobalF4;
+typedef RawU2 __attribute__((address_space(3))) *LdsStack;
+typedef RawU2 __attribute__((address_space(5))) *PrivateStack;
+__device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
 // LDS_ENTRIES is a kernel's trade between LDS per workgroup (occupancy) and how deep a tree goes
-// before entries land in private memory.
+// before entries land in private memory.  The two arrays live in the kernel (a __shared__ array of
+// LDS_ENTRIES * kTraceBlock entries and a local array of kSpillEntries); this holds their addresses.
 template <int LDS_ENTRIES>
 struct TraceStackT {
     static constexpr int kLdsEntries = LDS_ENTRIES;
-    uint2 *lds;         // LDS_ENTRIES * kTraceBlock entries
-    uint2 spill[kSpillEntries];
+    LdsStack lds;
+    PrivateStack spill;
+    __device__ inline TraceStackT(uint2 *shared_entries, uint2 *private_entries)
+        : lds((LdsStack)shared_entries), spill((PrivateStack)private_entries) {}
     __device__ inline void push(uint32_t sp, uint32_t node, float t0) {
-        uint2 e = make_uint2(node, __float_as_uint(t0));
+        RawU2 e = {node, __float_as_uint(t0)};
         if (sp < LDS_ENTRIES) lds[sp * kTraceBlock + threadIdx.x] = e;
         else if (sp < LDS_ENTRIES + kSpillEntries) spill[sp - LDS_ENTRIES] = e;
     }
     __device__ inline uint2 at(uint32_t sp) const {
-        if (sp < LDS_ENTRIES) return lds[sp * kTraceBlock + threadIdx.x];
-        if (sp < LDS_ENTRIES + kSpillEntries) return spill[sp - LDS_ENTRIES];
-        return make_uint2(0u, 0x7fc00000u);   // NaN entry distance: never entered
+        RawU2 e = {0u, 0x7fc00000u};          // NaN entry distance: never entered
+        if (sp < LDS_ENTRIES) e = lds[sp * kTraceBlock + threadIdx.x];
+        else if (sp < LDS_ENTRIES + kSpillEntries) e = spill[sp - LDS_ENTRIES];
+        return make_uint2(e.x, e.y);
     }
 };
 using TraceStack = TraceStackT<kLdsStackEntries>;
@@ -109,8 +124,8 @@ __device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, 
 
 // trimesh.cuh:14-43 on a pre-gathered record
 __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim) {
-    const float4 *q = reinterpret_cast<const float4 *>(rec);
-    float4 a = q[0], b = q[1], c = q[2];
+    GlobalF4 q = (GlobalF4)rec;
+    float4 a = load_f4(q, 0), b = load_f4(q, 1), c = load_f4(q, 2);
     V3 p0 = v3(a.x, a.y, a.z), e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
     V3 qv = cross(d, e2);
     float det = dot(e1, qv);
@@ -186,8 +201,8 @@ struct Traversal {
         bool need_pop = false;
         if (cn >= ct && cn >= ci) {
             if (is_node) {
-                const float4 *q = reinterpret_cast<const float4 *>(nodes + cur);
-                float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                GlobalF4 q = (GlobalF4)(nodes + cur);
+                float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
                 cnt.nodes++;
                 float t0l, t0r;
                 bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l);

@@ -61,8 +61,8 @@ template <bool ANY, bool DENSE>
 __global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[QueueTraceShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries> st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -237,8 +237,8 @@ template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    TraceStack st;
-    st.lds = s_stack;
+    uint2 spill_entries[kSpillEntries];
+    TraceStack st(s_stack, spill_entries);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
