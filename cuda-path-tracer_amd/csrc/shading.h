@@ -59,20 +59,28 @@ CPT_HD void vertex_transform_pdf(Vertex &v, const M4 &transform) {
     v.pdf /= length(cross(t, b));
 }
 
+// Mesh arrays are global memory; saying so in the pointer type turns the fetches below into global
+// loads (through the generic pointers of MeshDev they would be FLAT accesses).
+typedef const float __attribute__((address_space(1))) *GlobalFloats;
+typedef const uint32_t __attribute__((address_space(1))) *GlobalWords;
+CPT_D V3 load_v3(const V3 *base, uint32_t i) { GlobalFloats p = (GlobalFloats)(base + i); return V3{p[0], p[1], p[2]}; }
+CPT_D V2 load_v2(const V2 *base, uint32_t i) { GlobalFloats p = (GlobalFloats)(base + i); return V2{p[0], p[1]}; }
+
 // src/kernels/geometry/trimesh.cuh:45-72; texture coordinates are fetched only for materials that read them
 CPT_D Vertex get_vertex(const MeshDev &m, uint32_t prim, float ax, float ay, bool want_texcoord = false) {
-    uint32_t i0 = m.indices[prim * 3], i1 = m.indices[prim * 3 + 1], i2 = m.indices[prim * 3 + 2];
+    GlobalWords idx = (GlobalWords)(m.indices + prim * 3);
+    uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
     Vertex vert;
-    V3 pos0 = m.positions[i0], pos1 = m.positions[i1], pos2 = m.positions[i2];
+    V3 pos0 = load_v3(m.positions, i0), pos1 = load_v3(m.positions, i1), pos2 = load_v3(m.positions, i2);
     V3 e1 = pos1 - pos0, e2 = pos2 - pos0;
     float area = length(cross(e1, e2)) * 0.5f;
     vert.pdf = 1.0f / area / (float)m.num_triangles;
     vert.position = pos0 + ax * (pos1 - pos0) + ay * (pos2 - pos0);
-    V3 n0 = m.normals[i0], n1 = m.normals[i1], n2 = m.normals[i2];
+    V3 n0 = load_v3(m.normals, i0), n1 = load_v3(m.normals, i1), n2 = load_v3(m.normals, i2);
     vert.normal = normalize(n0 + ax * (n1 - n0) + ay * (n2 - n0));
     vert.texcoord = V2{0.0f, 0.0f};
     if (want_texcoord) {
-        V2 t0 = m.texcoords[i0], t1 = m.texcoords[i1], t2 = m.texcoords[i2];
+        V2 t0 = load_v2(m.texcoords, i0), t1 = load_v2(m.texcoords, i1), t2 = load_v2(m.texcoords, i2);
         vert.texcoord = t0 + ax * (t1 - t0) + ay * (t2 - t0);
     }
     return vert;
@@ -411,7 +419,8 @@ CPT_D V3 texture_fetch(const TextureDev &t, const float *srgb_to_linear, float u
     if (x0 < 0) x0 += w;
     if (y0 < 0) y0 += h;
     const int x1 = x0 + 1 == w ? 0 : x0 + 1, y1 = y0 + 1 == h ? 0 : y0 + 1;
-    const uint32_t t00 = t.texels[y0 * w + x0], t10 = t.texels[y0 * w + x1], t01 = t.texels[y1 * w + x0], t11 = t.texels[y1 * w + x1];
+    GlobalWords texels = (GlobalWords)t.texels;
+    const uint32_t t00 = texels[y0 * w + x0], t10 = texels[y0 * w + x1], t01 = texels[y1 * w + x0], t11 = texels[y1 * w + x1];
     auto channel = [&](int shift) {
         const float c00 = srgb_to_linear[(t00 >> shift) & 255u], c10 = srgb_to_linear[(t10 >> shift) & 255u];
         const float c01 = srgb_to_linear[(t01 >> shift) & 255u], c11 = srgb_to_linear[(t11 >> shift) & 255u];
