@@ -365,11 +365,11 @@ CPT_HD float glass_pdf(const BsdfDev &b, V3 wo, V3 wi) {
 CPT_HD V3 glass_eval(const BsdfDev &b, V3 wo, V3 wi) {
     float fr = fresnel(b.ior, wo, v3(0.0f, 0.0f, 1.0f));
     float ft = 1.0f - fr;
-    if (wo.z * wi.z <= 0.0f) {
-        float eta = wo.z >= 0.0f ? 1.0f / b.ior : b.ior;
-        return eta * eta * ft * b.specular;
-    }
-    return fr * b.diffuse;
+    // both products are formed and one is chosen: a branch that returns a multiple of one member or of
+    // another invites the compiler to pick the member by address, which parks the whole block in scratch
+    float eta = wo.z >= 0.0f ? 1.0f / b.ior : b.ior;
+    V3 transmitted = eta * eta * ft * b.specular, reflected = fr * b.diffuse;
+    return wo.z * wi.z <= 0.0f ? transmitted : reflected;
 }
 
 // tagged dispatch, src/kernels/bsdf/bsdf.cuh:24-82
