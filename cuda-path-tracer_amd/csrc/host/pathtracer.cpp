@@ -47,6 +47,7 @@ void PathTracer::BuildBuffers() {
     // about 7 MB of node and triangle records: beyond that the BVH no longer lives in the caches next to the CUs
     size_t triangles = 0;
     scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { triangles += mesh.GetMesh()->IndicesCount() / 3; });
+    scene_triangles_ = triangles;
     const bool dense = triangles >= 65536;
     if (dense != wf_dense_) { wf_dense_ = dense; wf_.capacity = 0; }      // the resident workgroup count is looked up again
     CPT_HIP(hipStreamSynchronize(stream_));
@@ -315,11 +316,14 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
 }
 
 void PathTracer::LaunchSample(const cpt::RenderParams &p) {
-    if (integrator_ == 2) {
+    // 3 = by scene size: the ray-queue variant wins once the BVH is far larger than the caches (measured: ahead at
+    // 10M triangles, behind at 1M), the persistent megakernel below that
+    const int integrator = integrator_ == 3 ? (scene_triangles_ >= 4000000 ? 2 : 0) : integrator_;
+    if (integrator == 2) {
         LaunchWavefront(p);
         return;
     }
-    if (integrator_ == 1) {
+    if (integrator == 1) {
         rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
         return;
     }

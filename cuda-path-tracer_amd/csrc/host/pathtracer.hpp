@@ -31,7 +31,7 @@ public:
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
-    // 2: wavefront (ray queues in HBM, one kernel sequence per bounce)
+    // 2: wavefront (ray queues in HBM, one kernel sequence per bounce); 3: 0 or 2 by the number of triangles
     void SetIntegrator(int mode) { integrator_ = mode; }
     // wavefront only: queue bounces before the persistent finishing launch; negative = queues only
     void SetWavefrontTail(int bounces) { wavefront_tail_ = bounces; }
@@ -84,6 +84,7 @@ private:
     bool built_ = false, has_camera_ = false;
     bool profile_build_ = false;
     int integrator_ = 0;
+    size_t scene_triangles_ = 0;
     uint32_t queue_parity_ = 0;
     int resident_blocks_ = 0;
     cpt::HipBuffer queue_;

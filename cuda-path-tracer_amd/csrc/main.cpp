@@ -90,6 +90,7 @@ int main(int argc, char **argv) {
 
         auto path_tracer = camera_object->AddComponent<PathTracer>(scene, film);
         path_tracer->SetMaxDepth(cmd_args.max_depth);
+        path_tracer->SetIntegrator(3);       // bounce-loop variant by scene size; the image does not depend on it
         path_tracer->SetCaptureName(cmd_args.capture_name);
         path_tracer->BuildBuffers();
 

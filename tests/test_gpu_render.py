@@ -217,7 +217,7 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
     must be identical, not merely close; so must their ray counts."""
     objs, cam = cornell(glass=True)
     imgs, rays = [], []
-    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1)):
+    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1), (3, None)):
         sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=depth)     # not a multiple of the 8x8 tiles
         tr.set_integrator(mode)
         if tail is not None:
