@@ -577,6 +577,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
     __shared__ uint8_t s_local[BLOCK];           // split b0+t: the parent stays inside this workgroup
     __shared__ uint32_t s_slot[BLOCK];           // exchange words of those splits
     __shared__ uint32_t s_box[BLOCK][6];         // boxes (order keys) of internal nodes b0 .. b1
+    __shared__ uint2 s_children[BLOCK];          // their children; rc == 0 marks a node this workgroup did not finish
     __shared__ uint32_t s_leaf[BLOCK][6];        // boxes (order keys) of this workgroup's leaves
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t b0 = blockIdx.x * BLOCK;
@@ -603,6 +604,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
     if (t == 0) s_key[0] = b0 > 0 ? keys[b0 - 1] : 0ull;
     if (t == 1) s_key[BLOCK + 1] = (b0 + BLOCK < n) ? keys[b0 + BLOCK] : 0ull;
     s_slot[t] = 0;
+    s_children[t] = make_uint2(0u, 0u);
     if (t == 0) s_park_count = 0;
     __syncthreads();
     // d(j) for j = b0-1+k, k = 0 .. BLOCK: -1 outside the key array
@@ -660,18 +662,19 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
         const uint32_t g = left_child ? r : l - 1;
         const uint32_t idx = internal ? (left_child ? r : l) : (n - 1) + i;
         const uint32_t gs = g - b0;
+        // A finished internal node leaves record and box in LDS (its number lies in this workgroup's
+        // range because its keys do); all of them are written to memory together after the climb, by
+        // every lane and in index order, instead of one scattered store per level by the few lanes
+        // that are still climbing.
         if (internal) {
-            nodes[idx] = AccelNode{lc, rc};
-            if (PARENTS) { parents[lc] = idx; parents[rc] = idx; }
-            float4 *gb = reinterpret_cast<float4 *>(bboxes + idx);
-            gb[0] = box_lo();
-            gb[1] = box_hi();
+            s_children[idx - b0] = make_uint2(lc, rc);
+            uint32_t *sb = s_box[idx - b0];
+            sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
         }
         if (!(gs < (uint32_t)BLOCK && s_local[gs] != 0)) {
-            // The parent spans several workgroups.  The node is complete (record and box stored);
-            // it meets its sibling in the second pass, which starts after this kernel has ended,
-            // so that the memory round trips of that exchange do not stall the lanes of this wave
-            // that still work in LDS.
+            // The parent spans several workgroups.  The node meets its sibling in the second pass,
+            // which starts after this kernel has ended, so that the memory round trips of that
+            // exchange do not stall the lanes of this wave that still work in LDS.
             const uint32_t slot = atomicAdd(&s_park_count, 1u);
             if (slot < carrier_limit) {
                 s_park[slot] = Carrier{l, r, idx, 0u};
@@ -686,10 +689,6 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
                 climb_global<PARENTS>(l, r, idx, lo, hi, false, lw, hw, keys, bboxes, nodes, parents, slots, merged, n);
             }
             break;
-        }
-        if (internal) {
-            uint32_t *sb = s_box[idx - b0];
-            sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
         }
         // LDS executes a wave's operations in issue order, so the box written above is in place
         // when another wave sees the exchange and reads it afterwards; only the compiler has to
@@ -718,6 +717,18 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
         internal = true;
     }
     __syncthreads();
+    {
+        const uint2 ch = s_children[t];
+        if (ch.y != 0u) {                                   // node b0 + t was finished here (a right child is never node 0)
+            const uint32_t idx = b0 + t;
+            nodes[idx] = AccelNode{ch.x, ch.y};
+            if (PARENTS) { parents[ch.x] = idx; parents[ch.y] = idx; }
+            const uint32_t *sb = s_box[t];
+            float4 *gb = reinterpret_cast<float4 *>(bboxes + idx);
+            gb[0] = make_float4(key_to_float(min(init_lo[0], sb[0])), key_to_float(min(init_lo[1], sb[1])), key_to_float(min(init_lo[2], sb[2])), merged.pmax.w);
+            gb[1] = make_float4(key_to_float(max(init_hi[0], sb[3])), key_to_float(max(init_hi[1], sb[4])), key_to_float(max(init_hi[2], sb[5])), merged.pmin.w);
+        }
+    }
     const uint32_t parked = min(s_park_count, carrier_limit);
     if (t < parked) carriers[(size_t)blockIdx.x * kCarriersPerGroup + t] = s_park[t];
     if (t == 0) carrier_counts[blockIdx.x] = parked;
