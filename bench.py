@@ -106,7 +106,9 @@ def main():
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--workload", default="cornell-box-glass",
                     help="cornell-box-glass (the metric's configuration, default) or a synthetic scene: heightfield-1m, heightfield-10m, soup-1m, soup-10m")
-    ap.add_argument("--integrator", type=int, default=0, help="0 persistent megakernel (default), 1 megakernel, 2 wavefront")
+    ap.add_argument("--integrator", type=int, default=3,
+                    help="3 by scene size (default: 0 for the Cornell box, 4 for the synthetic scenes), 0 persistent megakernel, 1 megakernel, "
+                         "2 wavefront, 4 persistent megakernel that shades partly finished waves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -138,6 +140,7 @@ def main():
         d = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box-glass")
         scene = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
         workload = f"cornell-box-glass {W}x{H}, max-depth {args.max_depth}, glass box"
+        scene_triangles = 36
     else:
         from helpers import synthetic_scene
         kind, _, size = args.workload.partition("-")
@@ -150,11 +153,14 @@ def main():
             scene.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
         scene.set_camera([0.5, 0.3, 0.1], [0.5, 0.0, 0.45], [0, 1, 0], 40.0, W, H)
         workload = f"synthetic {kind}, {len(objs[0]['indices']) // 3} triangles + emissive quad, {W}x{H}, max-depth {args.max_depth}"
+        scene_triangles = sum(len(o["indices"]) // 3 for o in objs)
     tracer = cpt.Tracer(scene, W, H, max_depth=args.max_depth)
     tracer.set_integrator(args.integrator)
     tracer.build_buffers()
-    kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish"}[args.integrator]
-    integrator_name = {0: "persistent megakernel (lane regeneration)", 1: "megakernel, one lane per pixel", 2: "wavefront (ray queues) + persistent tail"}[args.integrator]
+    integrator = args.integrator if args.integrator != 3 else (4 if scene_triangles >= 65536 else 0)     # what mode 3 resolves to in the library
+    kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow"}[integrator]
+    integrator_name = {0: "persistent megakernel (lane regeneration)", 1: "megakernel, one lane per pixel", 2: "wavefront (ray queues) + persistent tail",
+                       4: "persistent megakernel, traversal state kept across shading"}[integrator]
 
     def barrier():
         if world > 1:
@@ -238,7 +244,7 @@ def main():
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and args.workload == "cornell-box-glass" and args.integrator == 0 and (W, H, args.max_depth) == (1024, 1024, 8):
+            if os.path.exists(tpath) and args.workload == "cornell-box-glass" and integrator == 0 and (W, H, args.max_depth) == (1024, 1024, 8):
                 try:
                     traffic = json.load(open(tpath)).get("k_render_regen_hbm_bytes_per_launch")
                 except Exception:

@@ -340,7 +340,7 @@ int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth) { TRACER_OR_FAIL(t); 
 int cpt_tracer_set_channel(cpt_tracer *t, int channel) { TRACER_OR_FAIL(t); t->tracer->SetChannel(channel); return CPT_OK; }
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
     TRACER_OR_FAIL(t);
-    if (mode < 0 || mode > 3) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0, 1, 2 or 3");
+    if (mode < 0 || mode > 4) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0, 1, 2, 3 or 4");
     t->tracer->SetIntegrator(mode);
     return CPT_OK;
 }

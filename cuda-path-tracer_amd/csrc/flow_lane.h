@@ -1,0 +1,211 @@
+// One path per lane with the traversal state kept across the shading step: the wave leaves the
+// traversal loop as soon as enough of its lanes have a finished extension ray, shades those lanes
+// (new directions, new camera rays for ended paths) and goes back in, while the other lanes simply
+// resume the ray they were walking.  A lane traces its shadow ray and then its extension ray
+// inside the same loop, so the per-path order of operations is still the one of Trace
+// (src/kernels/integrator/path.cu:9-83): light sample, shadow ray, BSDF sample, extension ray.
+#pragma once
+#include "path_lane.h"
+
+namespace cpt {
+
+// Traversal of trace.h with the ray kind chosen per lane (closest hit for extension rays, any hit
+// for shadow rays).  The world-space ray is not kept here: its origin and direction are the
+// caller's path state.
+struct Flow {
+    uint32_t cur = kNoNode;
+    uint32_t sp = 0, sp_base = 0, inst_id = 0;
+    bool in_blas = false, found = false, world_fast = false;
+    float tmax = 0.0f;
+    V3 world_r = v3(0.0f);
+    RayFrame f;
+    const PackedNode *nodes = nullptr;
+    const TriRecord *tris = nullptr;
+    Hit hit;
+
+    __device__ inline bool walking() const { return cur != kNoNode; }
+
+    // What a ray needs before its first trip: the reciprocal direction (when the fast division applies)
+    // and the test of the top-level root box, which AccelTop::Intersect / Occlude do when they pop node 0.
+    struct Prepared { V3 r; bool fast, enters; };
+    static __device__ inline Prepared prepare(const SceneDev &sc, V3 ow, V3 dw, float reach) {
+        const AccelRoot troot = *sc.top_root;
+        RayFrame w;
+        w.set(ow, dw, troot.flags == 0);
+        float t0;
+        Prepared q;
+        q.r = w.r;
+        q.fast = w.fast;
+        q.enters = slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], w, kRayTMin, t0) && t0 < reach;
+        return q;
+    }
+    // Begins the ray (ow, dw) of reach `reach`; afterwards walking() is false if it missed everything at once.
+    __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float reach, const Prepared &q, LaneCounters &cnt) {
+        cnt.rays++;
+        tmax = reach;
+        sp = 0; sp_base = 0;
+        in_blas = false; found = false;
+        nodes = sc.top_nodes;
+        f.o = ow; f.d = dw; f.r = q.r; f.fast = q.fast;
+        world_r = q.r;
+        world_fast = q.fast;
+        cur = q.enters ? sc.top_root->ref : kNoNode;
+    }
+
+    // One trip for the wave.  (ow, dw): the lane's world-space ray; any: it is a shadow ray
+    // (AccelTop::Occlude, accel.cuh:152-173) and not an extension ray (AccelTop::Intersect,
+    // accel.cuh:124-150).  Returns true in the lanes whose ray ended in this trip.
+    template <class Stack>
+    __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, V3 ow, V3 dw, bool any) {
+        const bool alive = cur != kNoNode;
+        const bool is_node = alive && !(cur & kLeafBit);
+        const bool is_tri = alive && (cur & kLeafBit) && in_blas;
+        const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
+        const int cn = __popcll(__ballot(is_node)), ct = __popcll(__ballot(is_tri)), ci = __popcll(__ballot(is_inst));
+        bool need_pop = false, ended = false;
+        if (cn >= ct && cn >= ci) {
+            if (is_node) {
+                GlobalF4 q = (GlobalF4)(nodes + cur);
+                float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
+                cnt.nodes++;
+                float t0l, t0r;
+                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l);
+                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r);
+                if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                else need_pop = true;
+            }
+        } else if (ct >= ci) {
+            if (is_tri) {
+                float t, bv, bw;
+                uint32_t prim;
+                cnt.tris++;
+                need_pop = true;
+                if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
+                    found = true;
+                    if (any) {
+                        need_pop = false;
+                        cur = kNoNode;
+                        ended = true;
+                    } else {
+                        tmax = t;
+                        hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                    }
+                }
+            }
+        } else {
+            if (is_inst) {
+                inst_id = cur & ~kLeafBit;
+                const InstanceDev &in = sc.instances[inst_id];
+                M4 inv = in.transform_inv;
+                const MeshDev &m = sc.meshes[in.mesh];
+                nodes = m.nodes;
+                tris = m.tris;
+                AccelRoot r = m.root;
+                f.set(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
+                in_blas = true;
+                sp_base = sp;
+                float t0;
+                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, kRayTMin, t0) && t0 < tmax) cur = r.ref;
+                else need_pop = true;
+            }
+        }
+        if (need_pop) {
+            cur = kNoNode;
+            for (;;) {
+                if (in_blas && sp == sp_base) { in_blas = false; f.o = ow; f.d = dw; f.r = world_r; f.fast = world_fast; nodes = sc.top_nodes; }
+                if (sp == 0) break;
+                --sp;
+                uint2 e = st.at(sp);
+                if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+            }
+            ended = cur == kNoNode;
+        }
+        return ended;
+    }
+};
+
+// Path state beyond PathLane: the shadow ray in flight and what follows it
+struct FlowLane {
+    PathLane l;
+    V3 shadow_dir = v3(0.0f), pending = v3(0.0f);     // pending: light contribution, added when the shadow ray ends unoccluded
+    float shadow_tmax = 0.0f;
+    bool has_shadow = false, has_ext = false;         // rays still to be traced for the current path vertex
+    bool ext_traced = false;                          // Flow holds the result of this path's extension ray
+};
+
+// Shading for the lanes whose extension ray is finished (or whose path has nothing left to trace):
+// the part of Trace between two traversals (path.cu:13-55 for the first hit, :57-80 + :27-55 later).
+// Leaves the lane either ended (film written, l.alive false) or with has_shadow / has_ext set.
+template <bool MAPS>
+__device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, FlowLane &s, const Flow &t, LaneCounters &cnt) {
+    PathLane &l = s.l;
+    bool finish = !s.ext_traced || !t.found;
+    if (!finish) {
+        Surface surface = shading_surface<MAPS>(sc, t.hit, cnt);
+        if (l.primary) {
+            l.primary = false;
+            if (p.channel == 1) { l.color = surface.vertex.normal * 0.5f + v3(0.5f); finish = true; }
+            else { l.color = surface.bsdf.emission; if (!is_zero(l.color)) finish = true; }
+        } else if (!is_zero(surface.bsdf.emission) && dot(l.rd, surface.vertex.normal) < 0.0f) {
+            float mis_weight = 1.0f;
+            if (!l.last_specular) {
+                float light_pdf = surface.vertex.pdf * path_to_solid_angle_jacobian(l.ro, surface.vertex.position, surface.vertex.normal) *
+                                  sc.light_pick_pdf;
+                mis_weight = power_heuristic(l.last_pdf, light_pdf);
+            }
+            l.color = l.color + l.throughput * mis_weight * surface.bsdf.emission;
+            finish = true;
+        } else {
+            float rr_prop = gmin(gmax(luminance(l.throughput), 0.01f), 0.95f);
+            if (l.sampler.next1d() > rr_prop) finish = true;
+            else { l.throughput = l.throughput / rr_prop; l.depth++; }
+        }
+        if (!finish && !(l.depth < p.max_depth)) finish = true;
+        if (!finish) {
+            const V3 pos = surface.vertex.position;
+            Frame frame = Frame::from_normal(surface.vertex.normal);
+            V3 wo = frame.to_local(-l.rd);
+            s.has_shadow = false;
+            if (!bsdf_is_delta(surface.bsdf)) {
+                float r1 = l.sampler.next1d();
+                uint32_t index = min(f2u_sat(r1 * (float)sc.num_lights), sc.num_lights - 1);
+                V2 r2 = l.sampler.next2d();
+                LightSample ls = light_sample<MAPS>(sc, sc.lights[index], pos, r2);
+                ls.pdf *= sc.light_pick_pdf;
+                ls.weight = ls.weight / sc.light_pick_pdf;
+                if (ls.pdf > 0.0f) {
+                    V3 wi = frame.to_local(ls.dir);
+                    float bp = bsdf_pdf(surface.bsdf, wo, wi);
+                    float mis_weight = power_heuristic(ls.pdf, bp);
+                    s.pending = l.throughput * mis_weight * ls.weight * bsdf_eval(surface.bsdf, wo, wi);
+                    s.shadow_dir = ls.dir;
+                    s.shadow_tmax = ls.dist - kShadowRayEps;
+                    s.has_shadow = true;
+                }
+            }
+            float b1 = l.sampler.next1d();
+            V2 b2 = l.sampler.next2d();
+            BsdfSample bs = bsdf_sample(surface.bsdf, wo, b1, b2);
+            l.ro = pos;
+            s.has_ext = bs.pdf != 0.0f;
+            if (s.has_ext) {
+                l.throughput = l.throughput * bs.weight;
+                l.rd = frame.to_world(bs.wi);
+                l.last_pdf = bs.pdf;
+                l.last_specular = bs.lobe == kLobeSpecular;
+            }
+            s.ext_traced = false;
+            if (!s.has_shadow && !s.has_ext) finish = true;
+        }
+    }
+    if (finish) {
+        film_accumulate(p, l.pixel_index, l.color);
+        l.alive = false;
+        s.has_shadow = false;
+        s.has_ext = false;
+        s.ext_traced = false;
+    }
+}
+
+}  // namespace cpt

@@ -316,9 +316,10 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
 }
 
 void PathTracer::LaunchSample(const cpt::RenderParams &p) {
-    // 3 = by scene size: the ray-queue variant wins once the BVH is far larger than the caches (measured: ahead at
-    // 10M triangles, behind at 1M), the persistent megakernel below that
-    const int integrator = integrator_ == 3 ? (scene_triangles_ >= 4000000 ? 2 : 0) : integrator_;
+    // 3 = by scene size: the persistent kernel that shades partly finished waves (4) is ahead of both the plain
+    // persistent kernel and the ray queues once rays are long (measured at 1M and 10M triangles), and behind the
+    // plain one on a scene as small as the Cornell box
+    const int integrator = integrator_ == 3 ? (wf_dense_ ? 4 : 0) : integrator_;
     if (integrator == 2) {
         LaunchWavefront(p);
         return;
@@ -327,16 +328,18 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
         return;
     }
-    if (!queue_.Size() || resident_dense_ != wf_dense_) {
+    const bool flow = integrator == 4;
+    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_flow_ != flow) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, flow);
         resident_dense_ = wf_dense_;
+        resident_flow_ = flow;
     }
-    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, stream_), "render");
+    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, flow, stream_), "render");
     queue_parity_ ^= 1u;
 }
 

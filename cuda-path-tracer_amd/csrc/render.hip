@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "flow_lane.h"
 #include "path_lane.h"
 #include "segment_fetch.h"
 
@@ -164,6 +165,106 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
     flush_counters(sc, cnt, paths, s_cnt);
 }
 
+// The persistent kernel again, but a wave no longer waits for its slowest ray before it shades:
+// traversal state stays in registers across the shading step (flow_lane.h), lanes with a finished
+// extension ray are shaded and given their next rays as soon as they are half of the wave's live
+// lanes, and shadow rays run in the same loop as extension rays.  Lanes that enter the loop at
+// different times vote less often for the same kind of step, which costs more than the idle lanes
+// did on a scene that sits in the vector L1 (cornell-box-glass: 1.73 against 1.42 ms per sample);
+// with long rays through a large BVH it wins (heightfield 10M: 248 -> 342 Mpaths/s, soup 1M 73 -> 89).
+// Four waves per SIMD and 16 LDS stack entries for every scene: five waves measured the same, six spill.
+constexpr int kFlowWaves = 4;
+
+template <bool MAPS>
+__global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
+    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<kLdsStackEntries> st(s_stack, spill_entries);
+    LaneCounters cnt;
+    uint32_t paths = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    uint32_t *cursors = queue + parity * kCursorSetWords;
+    zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
+
+    SegmentFetchT<false> fetch;
+    FlowLane s;
+    Flow t;
+
+    for (;;) {
+        // ---- shade the lanes whose extension ray is done
+        if (s.l.alive && !t.walking()) flow_shade<MAPS>(sc, p, s, t, cnt);
+
+        // ---- hand new pixels to idle lanes
+        unsigned long long idle = __ballot(!s.l.alive);
+        while (idle != 0ull && !fetch.exhausted) {
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            const uint32_t rank = __popcll(idle & lt_mask);
+            const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
+            const uint32_t slot = fetch.entry(rank);
+            if (!s.l.alive && rank < take) {
+                const uint32_t tile = slot >> 6, k = slot & 63u;
+                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                if (px < p.width && py < p.height) {
+                    PathLane &l = s.l;
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
+                    l.alive = true; l.primary = true; l.last_specular = false;
+                    l.depth = 0; l.color = v3(0.0f); l.throughput = v3(1.0f);
+                    s.has_ext = true;
+                    paths++;
+                }
+            }
+            fetch.consumed += take;
+            idle = __ballot(!s.l.alive);
+        }
+        if (__ballot(s.l.alive) == 0ull) break;        // nothing in flight and every tile is handed out
+
+        // ---- begin the rays of the lanes just shaded: the shadow ray if there is one, else the extension
+        // ray; an extension ray that follows a shadow ray is prepared now, while the lanes are together,
+        // and begun inside the loop from what LDS keeps
+        auto ray_ended = [&]() {
+            if (s.has_shadow) {
+                if (!t.found) s.l.color = s.l.color + s.pending;
+                s.has_shadow = false;
+                if (s.has_ext) {
+                    Flow::Prepared q;
+                    q.r = v3(s_next[threadIdx.x], s_next[kTraceBlock + threadIdx.x], s_next[2 * kTraceBlock + threadIdx.x]);
+                    const uint32_t flags = __float_as_uint(s_next[3 * kTraceBlock + threadIdx.x]);
+                    q.fast = flags & 1u; q.enters = flags & 2u;
+                    t.begin(sc, s.l.ro, s.l.rd, kRayTMax, q, cnt);
+                }
+            }
+            if (!s.has_shadow && !t.walking()) { s.ext_traced = s.has_ext; s.has_ext = false; }
+        };
+        if (s.l.alive && !t.walking()) {
+            const Flow::Prepared ext = Flow::prepare(sc, s.l.ro, s.l.rd, kRayTMax);
+            if (s.has_shadow) {
+                if (s.has_ext) {
+                    s_next[threadIdx.x] = ext.r.x; s_next[kTraceBlock + threadIdx.x] = ext.r.y; s_next[2 * kTraceBlock + threadIdx.x] = ext.r.z;
+                    s_next[3 * kTraceBlock + threadIdx.x] = __uint_as_float((ext.fast ? 1u : 0u) | (ext.enters ? 2u : 0u));
+                }
+                t.begin(sc, s.l.ro, s.shadow_dir, s.shadow_tmax, Flow::prepare(sc, s.l.ro, s.shadow_dir, s.shadow_tmax), cnt);
+            } else {
+                t.begin(sc, s.l.ro, s.l.rd, kRayTMax, ext, cnt);
+            }
+            if (!t.walking()) ray_ended();
+        }
+
+        // ---- walk until enough lanes want shading
+        for (;;) {
+            const int walking = __popcll(__ballot(t.walking()));
+            const int waiting = __popcll(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
+            if (walking == 0 || (waiting > 0 && waiting >= walking)) break;
+            const bool shadow = s.has_shadow;
+            if (t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow)) ray_ended();
+        }
+    }
+    flush_counters(sc, cnt, paths, s_cnt);
+}
+
 // The batch query kernels hold one ray and no path state: few registers, so more waves per SIMD when
 // the LDS stack is shortened to match (deeper entries go to private memory).
 constexpr int kQueryWaves = 8;
@@ -275,12 +376,17 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
-int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, hipStream_t stream) {
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, bool flow, hipStream_t stream) {
     uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
     if (tiles == 0) return 0;
     uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? want : max_blocks;
     const dim3 grid(blocks), block(kTraceBlock);
+    if (flow) {
+        if (sc.textures) hipLaunchKernelGGL(k_render_flow<true>, grid, block, 0, stream, sc, p, queue, parity);
+        else hipLaunchKernelGGL(k_render_flow<false>, grid, block, 0, stream, sc, p, queue, parity);
+        return (int)hipGetLastError();
+    }
     if (sc.textures) {
         if (dense) hipLaunchKernelGGL((k_render_regen<true, true>), grid, block, 0, stream, sc, p, queue, parity);
         else hipLaunchKernelGGL((k_render_regen<true, false>), grid, block, 0, stream, sc, p, queue, parity);
@@ -291,10 +397,14 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device, bool dense) {
+int render_regen_resident_blocks(int device, bool dense, bool flow) {
     int per_cu = 0, other = 0, cus = 0;
     const void *with_maps = dense ? (const void *)k_render_regen<true, true> : (const void *)k_render_regen<true, false>;
     const void *without = dense ? (const void *)k_render_regen<false, true> : (const void *)k_render_regen<false, false>;
+    if (flow) {
+        with_maps = (const void *)k_render_flow<true>;
+        without = (const void *)k_render_flow<false>;
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_maps, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, without, kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
     if (other < per_cu) per_cu = other;

@@ -120,8 +120,11 @@ int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour,
  * path ends (default); 1 = one lane per pixel for the whole launch, the structure of the
  * reference's RenderKernel (src/kernels/integrator/path.cu:85-105); 2 = wavefront: path state and
  * ray queues in device memory, extend / shade / shadow kernels per bounce, traversal kernels that
- * refill idle lanes from the queue; 3 = 0 or 2 by scene size (2 from four million triangles on, where it is
- * the faster one on MI355X).  Same image in all of them. */
+ * refill idle lanes from the queue; 4 = persistent megakernel that keeps a lane's traversal state
+ * across the shading step, so a wave shades the lanes whose ray is finished as soon as they are
+ * half of its live lanes and shadow rays share the loop with extension rays; 3 = 0 or 4 by scene
+ * size (4 from 65,536 triangles on, where it is the fastest of all on MI355X).  Same image in all
+ * of them. */
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
 /* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
  * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette

@@ -217,7 +217,7 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
     must be identical, not merely close; so must their ray counts."""
     objs, cam = cornell(glass=True)
     imgs, rays = [], []
-    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1), (3, None)):
+    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1), (3, None), (4, None)):
         sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=depth)     # not a multiple of the 8x8 tiles
         tr.set_integrator(mode)
         if tail is not None:
@@ -235,7 +235,7 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
 def test_wavefront_sum_mode_and_normal_channel(cpt):
     objs, cam = cornell(glass=False)
     out = []
-    for mode in (0, 2):
+    for mode in (0, 2, 4):
         sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=4)
         tr.set_integrator(mode)
         buf = cpt.DeviceArray((64, 64, 4), np.float32); buf.zero()
@@ -245,5 +245,6 @@ def test_wavefront_sum_mode_and_normal_channel(cpt):
         tr.set_channel(1)
         tr.update(1)
         out.append((a, tr.film()))
-    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
-    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    for k in (1, 2):
+        assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
+        assert np.array_equal(out[0][1].view(np.uint32), out[k][1].view(np.uint32))
