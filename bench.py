@@ -254,6 +254,13 @@ def main():
                                   "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         if world == 1 and not args.no_lbvh:
             result["lbvh"] = {"1M": lbvh_timings(cpt, 1_000_000), "10M": lbvh_timings(cpt, 10_000_000)}
+            # what a kernel that only streams reaches on this device (1 GiB copied, read + written bytes counted),
+            # and the 10M build's 312 bytes per primitive against that instead of the nominal peak
+            rate = C.c_double(0.0)
+            cpt.check(cpt.lib.cpt_stream_copy_rate(1 << 30, 10, C.byref(rate)))
+            result["lbvh"]["stream_copy_gb_per_s"] = round(rate.value, 1)
+            med = result["lbvh"]["10M"]["build_ms"]
+            result["lbvh"]["10M"]["frac_of_stream_copy"] = round(312.0 * 10_000_000 / (med * 1e-3) / 1e9 / rate.value, 4)
         if world == 1 and not args.no_cpu_baseline and args.workload == "cornell-box-glass":
             result["cpu_baseline"] = cpu_baseline(W, H, args.max_depth)
         print(json.dumps(result), flush=True)

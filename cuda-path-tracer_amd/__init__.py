@@ -92,6 +92,7 @@ _sig("cpt_tracer_counters", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_counters", C.c_int, [_vp])
 _sig("cpt_tracer_build_stage_ms", C.c_int, [_vp, _vp])
 _sig("cpt_selftest_division", C.c_int, [C.c_uint64, C.c_uint32, _vp])
+_sig("cpt_stream_copy_rate", C.c_int, [C.c_uint64, C.c_int, _vp])
 _sig("cpt_write_exr", C.c_int, [C.c_char_p, _f32, C.c_uint32, C.c_uint32])
 _sig("cpt_image_load", C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_size_t])
 _sig("cpt_image_save_png", C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32])

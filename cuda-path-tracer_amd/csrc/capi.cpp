@@ -474,6 +474,31 @@ int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches) {
     });
 }
 
+int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s) {
+    if (!gb_per_s || repeats < 1 || bytes < 16) return Fail(CPT_ERR_INVALID, "cpt_stream_copy_rate: bad argument");
+    return Guard([&] {
+        cpt::HipBuffer src(bytes), dst(bytes);
+        src.Zero();
+        hipEvent_t e0, e1;
+        CPT_HIP(hipEventCreate(&e0));
+        CPT_HIP(hipEventCreate(&e1));
+        int rc = cpt::launch_stream_copy(src.GpuData(), dst.GpuData(), bytes, nullptr);       // warm-up
+        if (rc == 0) {
+            CPT_HIP(hipEventRecord(e0, nullptr));
+            for (int k = 0; k < repeats && rc == 0; k++) rc = cpt::launch_stream_copy(src.GpuData(), dst.GpuData(), bytes, nullptr);
+            CPT_HIP(hipEventRecord(e1, nullptr));
+            CPT_HIP(hipEventSynchronize(e1));
+        }
+        float ms = 0.0f;
+        if (rc == 0) CPT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc != 0) return HipFail((hipError_t)rc, "stream_copy");
+        *gb_per_s = 2.0 * (double)(bytes / 16 * 16) * repeats / ((double)ms * 1e-3) / 1e9;     // bytes read + bytes written
+        return (int)CPT_OK;
+    });
+}
+
 int cpt_image_load(const char *path, uint32_t *width, uint32_t *height, uint32_t *rgba, size_t capacity) {
     if (!path || !width || !height) return Fail(CPT_ERR_INVALID, "cpt_image_load: null argument");
     return Guard([&] {

@@ -25,6 +25,9 @@ int render_regen_resident_blocks(int device, bool dense, bool flow);
 // `pairs` operand pairs; adds the number of differing results to *d_mismatches (device memory).
 int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_mismatches, hipStream_t stream);
 
+// Copies bytes / 16 * 16 bytes from src to dst (both 16-byte aligned device memory) with a plain streaming kernel.
+int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t stream);
+
 // rays: device array of n * 8 floats (origin.xyz, tmin, direction.xyz, tmax).
 // inst/prim receive 0xffffffff on a miss; t receives the hit distance (or the input tmax);
 // t and uv may be null.

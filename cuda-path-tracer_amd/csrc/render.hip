@@ -357,7 +357,23 @@ __global__ void __launch_bounds__(256) k_div_selftest(uint32_t seed, uint32_t pe
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// Plain copy, 16 bytes per lane and trip, grid-stride: the rate the memory system gives a kernel that does
+// nothing but stream, to set next to the 8 TB/s nominal peak.
+__global__ void __launch_bounds__(256) k_stream_copy(const RawF4 *__restrict__ src, RawF4 *__restrict__ dst, unsigned long long n16) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t stream) {
+    const unsigned long long n16 = bytes / 16;
+    if (n16 == 0) return 0;
+    unsigned long long want = (n16 + 256 * 4 - 1) / (256 * 4);         // four trips per lane
+    const uint32_t blocks = (uint32_t)(want < 1u ? 1u : (want > 0x7fffffffull ? 0x7fffffffull : want));
+    hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, stream, (const RawF4 *)src, (RawF4 *)dst, n16);
+    return (int)hipGetLastError();
+}
 
 int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_mismatches, hipStream_t stream) {
     const uint32_t per_thread = 4096;

@@ -181,6 +181,11 @@ int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
  * pairs from its admissible range through both and reports how many differ (expected: 0). */
 int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches);
 
+/* Device measurement with no counterpart in the reference: copies `bytes` of device memory `repeats`
+ * times with a plain streaming kernel and reports (bytes read + bytes written) per second, the
+ * rate to set next to the nominal HBM peak when judging the build and traversal kernels. */
+int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s);
+
 /* Standalone OpenEXR writer used by Film::SaveTo (src/pathtracer/film.cpp:61-68). */
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height);
 
