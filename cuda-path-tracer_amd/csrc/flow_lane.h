@@ -61,7 +61,7 @@ struct Flow {
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
         const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
-        const int cn = __popcll(__ballot(is_node)), ct = __popcll(__ballot(is_tri)), ci = __popcll(__ballot(is_inst));
+        const int cn = lanes_in(__ballot(is_node)), ct = lanes_in(__ballot(is_tri)), ci = lanes_in(__ballot(is_inst));
         bool need_pop = false, ended = false;
         if (cn >= ct && cn >= ci) {
             if (is_node) {

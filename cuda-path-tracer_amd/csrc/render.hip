@@ -255,8 +255,8 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 
         // ---- walk until enough lanes want shading
         for (;;) {
-            const int walking = __popcll(__ballot(t.walking()));
-            const int waiting = __popcll(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
+            const int walking = lanes_in(__ballot(t.walking()));
+            const int waiting = lanes_in(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
             if (walking == 0 || (waiting > 0 && waiting >= walking)) break;
             const bool shadow = s.has_shadow;
             if (t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow)) ray_ended();

@@ -63,6 +63,10 @@ using TraceStack = TraceStackT<kLdsStackEntries>;
 
 struct Hit { uint32_t inst, prim; float u, v; };
 
+// Lane count of a ballot as a 32-bit scalar: the 64-bit population count is carried as a 64-bit value, and
+// ordering two of those is a vector compare on this target (there is no scalar 64-bit less-than).
+__device__ inline int lanes_in(unsigned long long mask) { return __builtin_popcount((uint32_t)mask) + __builtin_popcount((uint32_t)(mask >> 32)); }
+
 // ---- correctly rounded a / d from a correctly rounded reciprocal ---------------------------------
 // With r = RN(1/d):  q0 = RN(a*r) is within 2 ulp of a/d; one residual step
 // q1 = RN(q0 + RN(a - q0*d) * r) makes it faithful (error < 1 ulp); for a faithful q1 the residual
@@ -197,7 +201,7 @@ struct Traversal {
         const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
         const unsigned long long mn = __ballot(is_node), mt = __ballot(is_tri), mi = __ballot(is_inst);
         if ((mn | mt | mi) == 0ull) return false;
-        const int cn = __popcll(mn), ct = __popcll(mt), ci = __popcll(mi);
+        const int cn = lanes_in(mn), ct = lanes_in(mt), ci = lanes_in(mi);
         bool need_pop = false;
         if (cn >= ct && cn >= ci) {
             if (is_node) {

@@ -47,6 +47,29 @@ def test_cornell_against_oracle(cpt, glass, depth, bsdf):
     assert abs(c["rays"] - int(ocnt[0])) <= 0.002 * int(ocnt[0])         # same paths up to a few flipped decisions
 
 
+def test_metric_configuration_at_full_size(cpt):
+    """The configuration the benchmark is quoted on (cornell-box-glass, 1024x1024, max-depth 8), a few samples
+    against the oracle.  Every difference starts from a last-ulp difference in sinf/cosf/powf that flips one
+    decision of one path; at 3 samples per pixel a single flipped firefly moves the L2 norm of the whole
+    image, so the bar here is the fraction of pixels that differ at all (measured: 0.035 %), the channel
+    means and the ray count."""
+    objs, cam = cornell(glass=True)
+    osc = OracleScene(objs, cam)
+    d = os.path.join(SCENES, "cornell-box-glass")
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+    tr = cpt.Tracer(sc, 1024, 1024, max_depth=8).build_buffers()
+    tr.update(3)
+    img = tr.film()
+    ref, ocnt = osc.render(1024, 1024, 1, 4, 8, nthreads=min(16, os.cpu_count() or 1))
+    assert np.all(np.isfinite(img)) and np.array_equal(img[..., 3], ref[..., 3])
+    differing = np.any(np.abs(img[..., :3] - ref[..., :3]) > 1e-5 * np.maximum(np.abs(ref[..., :3]), 1e-3), axis=-1).mean()
+    assert differing < 2e-3, differing
+    assert np.allclose(img[..., :3].mean(axis=(0, 1)), ref[..., :3].mean(axis=(0, 1)), rtol=MEAN_TOL)
+    c = tr.counters()
+    assert c["paths"] == 3 * 1024 * 1024
+    assert abs(c["rays"] - int(ocnt[0])) <= 1e-4 * int(ocnt[0])
+
+
 def test_transformed_instances_render(cpt):
     """Shading through object transforms: normals by the inverse transpose, the moved light's
     sampling and pdf (instance.cuh:14-27, light/geometry.cuh:9-31), against the oracle."""
