@@ -54,6 +54,7 @@ _sig("cpt_builder_build", C.c_int, [_vp, _vp, _vp, _vp, _f32, C.c_uint32, _vp, _
 _sig("cpt_scene_create", _vp, [])
 _sig("cpt_scene_destroy", None, [_vp])
 _sig("cpt_scene_load_obj", C.c_int, [_vp, C.c_char_p, C.c_int])
+_sig("cpt_scene_load_obj_cached", C.c_int, [_vp, C.c_char_p, C.c_int, _vp])
 _sig("cpt_scene_load_json", C.c_int, [_vp, C.c_char_p])
 _sig("cpt_scene_load_xml", C.c_int, [_vp, C.c_char_p])
 _sig("cpt_scene_add_object", C.c_int, [_vp, C.c_char_p, _f32, _f32, _f32, C.c_uint32, _u32, C.c_uint32, _f32, _vp])
@@ -195,8 +196,16 @@ class Scene:
         except Exception:
             pass
 
-    def load_obj(self, path, bsdf_type=2):
-        check(lib.cpt_scene_load_obj(self.h, os.fsencode(path), bsdf_type))
+    def load_obj(self, path, bsdf_type=2, cache=False):
+        """cache=True reads and keeps <path>.cptcache (a binary copy of the parsed scene); self.from_cache tells
+        whether the last load came from it."""
+        if cache:
+            hit = C.c_int(0)
+            check(lib.cpt_scene_load_obj_cached(self.h, os.fsencode(path), bsdf_type, C.byref(hit)))
+            self.from_cache = bool(hit.value)
+        else:
+            check(lib.cpt_scene_load_obj(self.h, os.fsencode(path), bsdf_type))
+            self.from_cache = False
         return self
 
     def load_json(self, path):

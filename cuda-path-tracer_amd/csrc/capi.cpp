@@ -171,6 +171,15 @@ int cpt_scene_load_obj(cpt_scene *s, const char *path, int bsdf_type) {
     if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_obj: null argument");
     return Guard([&] { return LoadObjScene(s->scene, path, bsdf_type) ? CPT_OK : Fail(CPT_ERR_IO, std::string("failed to load obj file '") + path + "'"); });
 }
+int cpt_scene_load_obj_cached(cpt_scene *s, const char *path, int bsdf_type, int *from_cache) {
+    if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_obj_cached: null argument");
+    return Guard([&] {
+        bool hit = false;
+        if (!LoadObjSceneCached(s->scene, path, bsdf_type, &hit)) return Fail(CPT_ERR_IO, std::string("failed to load obj file '") + path + "'");
+        if (from_cache) *from_cache = hit ? 1 : 0;
+        return (int)CPT_OK;
+    });
+}
 int cpt_scene_load_json(cpt_scene *s, const char *path) {
     if (!s || !path) return Fail(CPT_ERR_INVALID, "cpt_scene_load_json: null argument");
     return Guard([&] { return LoadJsonScene(s->scene, path) ? CPT_OK : Fail(CPT_ERR_IO, std::string("failed to load json file '") + path + "'"); });

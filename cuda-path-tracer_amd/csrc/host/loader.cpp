@@ -437,7 +437,9 @@ V3 Vec3FromCommaSplittedStr(const char *str) {       // src/scene/loader.cpp:99-
 
 }  // namespace
 
-bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type) {
+bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type) { return LoadObjScene(scene, path, bsdf_type, nullptr); }
+
+bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type, std::vector<std::filesystem::path> *material_libraries) {
     std::string text;
     if (!ReadFile(path, text)) return false;
     auto base_dir = path.parent_path();
@@ -547,6 +549,7 @@ bool LoadObjScene(Scene &scene, const std::filesystem::path &path, int bsdf_type
                 cur_material = found == material_index.end() ? -1 : found->second;
             } else if (it.kind == Item::kMtlLib) {
                 ParseMtl(base_dir / it.text, in_materials, material_index);
+                if (material_libraries) material_libraries->push_back(base_dir / it.text);
             } else if (it.kind == Item::kGroup) {
                 flush();
                 cur.name = it.text;

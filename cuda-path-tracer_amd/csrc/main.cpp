@@ -1,8 +1,9 @@
 // Command-line renderer with the reference's interface (src/main.cpp:8-134), headless only:
 //   cuda-pathtracer <obj> <json|xml> [--ui 0|1] [--max-depth N] [--max-spp N] [--output|-o NAME]
-//                   [--bsdf-type lambert|phong|blinn-phong|microfacet]
+//                   [--bsdf-type lambert|phong|blinn-phong|microfacet] [--scene-cache 0|1]
 // The interactive window (--ui 1) does not exist in this build; the flag is accepted and ignored
 // with a note, everything else behaves as the reference's --ui 0 path and writes NAME.exr.
+// --scene-cache 1 (not in the reference) keeps a binary copy of the parsed scene next to the .obj.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,7 @@ int main(int argc, char **argv) {
         const char *capture_name = "capture";
         const char *bsdf_type = "blinn-phong";
         int bsdf_type_i = 2;
+        bool scene_cache = false;
     } cmd_args;
 
     if (argc < 3) {
@@ -31,6 +33,7 @@ int main(int argc, char **argv) {
         std::cout << "  --max-spp       max ray tracing spp (default -1, which renders 65536)\n";
         std::cout << "  --output | -o   output .exr name (default 'capture')\n";
         std::cout << "  --bsdf-type     which BSDF to use (default 'blinn-phong')\n";
+        std::cout << "  --scene-cache   0 or 1 (default 0): keep and reuse <obj>.cptcache, a binary copy of the parsed scene\n";
         return -1;
     }
     for (int i = 3; i < argc; i++) {
@@ -45,6 +48,8 @@ int main(int argc, char **argv) {
             cmd_args.capture_name = argv[++i];
         } else if (strcmp(argv[i], "--bsdf-type") == 0 && has_value) {
             cmd_args.bsdf_type = argv[++i];
+        } else if (strcmp(argv[i], "--scene-cache") == 0 && has_value) {
+            cmd_args.scene_cache = std::atoi(argv[++i]);
         }
     }
     const char *bsdf_type_names[] = {"lambert", "phong", "blinn-phong", "microfacet"};
@@ -63,10 +68,12 @@ int main(int argc, char **argv) {
     }
 
     Scene scene{};
-    if (!LoadObjScene(scene, obj_path, cmd_args.bsdf_type_i)) {
+    bool from_cache = false;
+    if (!(cmd_args.scene_cache ? LoadObjSceneCached(scene, obj_path, cmd_args.bsdf_type_i, &from_cache) : LoadObjScene(scene, obj_path, cmd_args.bsdf_type_i))) {
         std::cout << "failed to load obj file '" << obj_path << "'" << std::endl;
         return -1;
     }
+    if (from_cache) std::cout << "scene read from '" << obj_path.string() << ".cptcache'" << std::endl;
     if (extra_path.extension() == ".json") {
         if (!LoadJsonScene(scene, extra_path)) {
             std::cout << "failed to load json file '" << extra_path << "'" << std::endl;

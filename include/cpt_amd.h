@@ -85,6 +85,11 @@ int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void 
 cpt_scene *cpt_scene_create(void);
 void cpt_scene_destroy(cpt_scene *s);
 int cpt_scene_load_obj(cpt_scene *s, const char *path, int bsdf_type);
+/* The same scene through <path>.cptcache, a binary copy of the parsed .obj that is read when it was written
+ * from the .obj and material libraries as they are now (sizes, modification times) and for this bsdf_type,
+ * and (re)written otherwise; material maps always come from their image files.  *from_cache (may be NULL)
+ * receives 1 or 0.  No counterpart in the reference (src/scene/loader.cpp:144-260 parses the text every run). */
+int cpt_scene_load_obj_cached(cpt_scene *s, const char *path, int bsdf_type, int *from_cache);
 int cpt_scene_load_json(cpt_scene *s, const char *path);
 int cpt_scene_load_xml(cpt_scene *s, const char *path);
 /* adds one object (mesh + material); transform16 may be NULL (identity) */

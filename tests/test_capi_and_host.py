@@ -120,6 +120,59 @@ def test_large_obj_parsed_in_pieces_matches_independent_reader(cpt, tmp_path):
             assert np.array_equal(a[k], b[k]), (a["name"], k)
 
 
+def test_binary_scene_copy_round_trip_and_staleness(cpt, tmp_path):
+    """load_obj(cache=True): the first load parses and writes <obj>.cptcache, the second reads it and gives the
+    same objects bit for bit (names, arrays, materials, maps); a changed .obj, a changed .mtl, another bsdf_type
+    or a damaged copy are not served from it."""
+    import shutil, time
+    from helpers import textured_box_files
+    obj, cam, maps = textured_box_files(str(tmp_path))
+    plain = cpt.Scene().load_obj(obj, 2)
+    first = cpt.Scene().load_obj(obj, 2, cache=True)
+    assert not first.from_cache and os.path.exists(obj + ".cptcache")
+    second = cpt.Scene().load_obj(obj, 2, cache=True)
+    assert second.from_cache
+
+    def same(a, b):
+        oa, ob = a.objects(), b.objects()
+        assert [o["name"] for o in oa] == [o["name"] for o in ob] and len(oa) > 1
+        for x, y in zip(oa, ob):
+            for k in ("positions", "normals", "texcoords", "indices", "material", "transform"):
+                assert np.array_equal(x[k].view(np.uint32) if x[k].dtype == np.float32 else x[k], y[k].view(np.uint32) if y[k].dtype == np.float32 else y[k]), (x["name"], k)
+        for i in range(len(oa)):
+            for which in range(3):
+                ma, mb = a.object_map(i, which), b.object_map(i, which)
+                assert (ma is None) == (mb is None) and (ma is None or np.array_equal(ma, mb))
+    same(plain, first)
+    same(plain, second)
+    assert any(second.object_map(i, 0) is not None for i in range(len(second.objects())))      # maps are there after a cached load
+
+    # another bsdf_type: parsed again, copy rewritten for it
+    other = cpt.Scene().load_obj(obj, 0, cache=True)
+    assert not other.from_cache
+    assert cpt.Scene().load_obj(obj, 0, cache=True).from_cache
+    assert not cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+    # the material library changes
+    mtl = [f for f in os.listdir(tmp_path) if f.endswith(".mtl")][0]
+    with open(tmp_path / mtl, "a") as f:
+        f.write("\n# touched\n")
+    assert not cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+    assert cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+    # the .obj changes (same size, later time)
+    st = os.stat(obj)
+    os.utime(obj, ns=(st.st_atime_ns, st.st_mtime_ns + 2_000_000_000))
+    assert not cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+    # a truncated copy is ignored and replaced
+    blob = open(obj + ".cptcache", "rb").read()
+    open(obj + ".cptcache", "wb").write(blob[: len(blob) // 2])
+    third = cpt.Scene().load_obj(obj, 2, cache=True)
+    assert not third.from_cache
+    same(plain, third)
+    open(obj + ".cptcache", "wb").write(blob + b"x")
+    assert not cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+    assert cpt.Scene().load_obj(obj, 2, cache=True).from_cache
+
+
 def test_number_grammar_of_the_reference_reader(cpt, tmp_path):
     """tinyobjloader's tryParseDouble (tiny_obj_loader.h:866-996): what is not a number by its
     grammar leaves the default 0, whatever strtof would make of it."""
