@@ -54,7 +54,8 @@ struct Flow {
 
     // One trip for the wave.  (ow, dw): the lane's world-space ray; any: it is a shadow ray
     // (AccelTop::Occlude, accel.cuh:152-173) and not an extension ray (AccelTop::Intersect,
-    // accel.cuh:124-150).  Returns true in the lanes whose ray ended in this trip.
+    // accel.cuh:124-150).  A lane whose ray ends is left with walking() false.  Returns false, in every
+    // lane, when no lane of the wave had a step to take.
     template <class Stack>
     __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, V3 ow, V3 dw, bool any) {
         const bool alive = cur != kNoNode;
@@ -62,7 +63,7 @@ struct Flow {
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
         const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
         const int cn = lanes_in(__ballot(is_node)), ct = lanes_in(__ballot(is_tri)), ci = lanes_in(__ballot(is_inst));
-        bool need_pop = false, ended = false;
+        bool need_pop = false;
         if (cn >= ct && cn >= ci) {
             if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
@@ -86,7 +87,6 @@ struct Flow {
                     if (any) {
                         need_pop = false;
                         cur = kNoNode;
-                        ended = true;
                     } else {
                         tmax = t;
                         hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
@@ -119,9 +119,8 @@ struct Flow {
                 uint2 e = st.at(sp);
                 if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
             }
-            ended = cur == kNoNode;
         }
-        return ended;
+        return cn + ct + ci != 0;
     }
 };
 

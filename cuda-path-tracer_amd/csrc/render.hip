@@ -253,13 +253,17 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
             if (!t.walking()) ray_ended();
         }
 
-        // ---- walk until enough lanes want shading
-        for (;;) {
+        // ---- walk until enough lanes want shading.  Rays end at scattered trips; looking after them (light
+        // contribution, the extension ray that follows a shadow ray) and counting lanes every trip would put that
+        // code into nearly every trip for one or two lanes, so it runs every fourth trip and when nothing moves.
+        for (uint32_t trip = 0;; trip++) {
+            const bool shadow = s.has_shadow;
+            const bool moved = t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow);
+            if (moved && (trip & 3u) != 3u) continue;
+            if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
             const int waiting = lanes_in(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
-            if (walking == 0 || (waiting > 0 && waiting >= walking)) break;
-            const bool shadow = s.has_shadow;
-            if (t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow)) ray_ended();
+            if (walking == 0 || waiting >= walking) break;
         }
     }
     flush_counters(sc, cnt, paths, s_cnt);
