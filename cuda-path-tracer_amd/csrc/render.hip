@@ -167,13 +167,17 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 
 // The persistent kernel again, but a wave no longer waits for its slowest ray before it shades:
 // traversal state stays in registers across the shading step (flow_lane.h), lanes with a finished
-// extension ray are shaded and given their next rays as soon as they are half of the wave's live
-// lanes, and shadow rays run in the same loop as extension rays.  Lanes that enter the loop at
+// extension ray are shaded and given their next rays as soon as they are three eighths of the
+// wave's live lanes, and shadow rays run in the same loop as extension rays.  Lanes that enter the loop at
 // different times vote less often for the same kind of step, which costs more than the idle lanes
-// did on a scene that sits in the vector L1 (cornell-box-glass: 1.73 against 1.42 ms per sample);
-// with long rays through a large BVH it wins (heightfield 10M: 248 -> 342 Mpaths/s, soup 1M 73 -> 89).
+// did on a scene that sits in the vector L1 (cornell-box-glass: 1.66 against 1.42 ms per sample);
+// with long rays through a large BVH it wins (heightfield 10M: 248 -> 395 Mpaths/s, soup 1M 73 -> 104).
 // Four waves per SIMD and 16 LDS stack entries for every scene: five waves measured the same, six spill.
 constexpr int kFlowWaves = 4;
+#ifndef FLOW_NUM
+#define FLOW_NUM 3
+#endif
+constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
 template <bool MAPS>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
@@ -255,15 +259,15 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 
         // ---- walk until enough lanes want shading.  Rays end at scattered trips; looking after them (light
         // contribution, the extension ray that follows a shadow ray) and counting lanes every trip would put that
-        // code into nearly every trip for one or two lanes, so it runs every fourth trip and when nothing moves.
+        // code into nearly every trip for one or two lanes, so it runs every sixteenth trip and when nothing moves.
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = s.has_shadow;
             const bool moved = t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow);
-            if (moved && (trip & 3u) != 3u) continue;
+            if (moved && (trip & 15u) != 15u) continue;
             if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
             const int waiting = lanes_in(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
-            if (walking == 0 || waiting >= walking) break;
+            if (walking == 0 || (waiting > 0 && waiting * 8 >= (walking + waiting) * kFlowShadeEighths)) break;
         }
     }
     flush_counters(sc, cnt, paths, s_cnt);
