@@ -349,7 +349,7 @@ int cpt_tracer_set_max_depth(cpt_tracer *t, int max_depth) { TRACER_OR_FAIL(t); 
 int cpt_tracer_set_channel(cpt_tracer *t, int channel) { TRACER_OR_FAIL(t); t->tracer->SetChannel(channel); return CPT_OK; }
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
     TRACER_OR_FAIL(t);
-    if (mode < 0 || mode > 4) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0, 1, 2, 3 or 4");
+    if (mode < 0 || mode > 5) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_integrator: mode must be 0 to 5");
     t->tracer->SetIntegrator(mode);
     return CPT_OK;
 }

@@ -40,8 +40,8 @@ struct Flow {
         return q;
     }
     // Begins the ray (ow, dw) of reach `reach`; afterwards walking() is false if it missed everything at once.
-    __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float reach, const Prepared &q, LaneCounters &cnt) {
-        cnt.rays++;
+    __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float reach, const Prepared &q, LaneCounters &cnt, bool count = true) {
+        if (count) cnt.rays++;
         tmax = reach;
         sp = 0; sp_base = 0;
         in_blas = false; found = false;
@@ -52,12 +52,12 @@ struct Flow {
         cur = q.enters ? sc.top_root->ref : kNoNode;
     }
 
-    // One trip for the wave.  (ow, dw): the lane's world-space ray; any: it is a shadow ray
-    // (AccelTop::Occlude, accel.cuh:152-173) and not an extension ray (AccelTop::Intersect,
-    // accel.cuh:124-150).  A lane whose ray ends is left with walking() false.  Returns false, in every
-    // lane, when no lane of the wave had a step to take.
-    template <class Stack>
-    __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, V3 ow, V3 dw, bool any) {
+    // One trip for the wave.  world(ow, dw) gives the lane's world-space ray (asked for only when the lane
+    // enters or leaves an instance); any: it is a shadow ray (AccelTop::Occlude, accel.cuh:152-173) and not
+    // an extension ray (AccelTop::Intersect, accel.cuh:124-150).  A lane whose ray ends is left with
+    // walking() false.  Returns false, in every lane, when no lane of the wave had a step to take.
+    template <class Stack, class World>
+    __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, World world, bool any) {
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -102,6 +102,8 @@ struct Flow {
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
+                V3 ow, dw;
+                world(ow, dw);
                 f.set(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
@@ -113,7 +115,7 @@ struct Flow {
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
-                if (in_blas && sp == sp_base) { in_blas = false; f.o = ow; f.d = dw; f.r = world_r; f.fast = world_fast; nodes = sc.top_nodes; }
+                if (in_blas && sp == sp_base) { in_blas = false; world(f.o, f.d); f.r = world_r; f.fast = world_fast; nodes = sc.top_nodes; }
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);

@@ -328,18 +328,18 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         rc_check(cpt::launch_render(scene_dev_, p, stream_), "render");
         return;
     }
-    const bool flow = integrator == 4;
-    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_flow_ != flow) {
+    const int variant = integrator == 4 ? 1 : (integrator == 5 ? 2 : 0);
+    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, flow);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant);
         resident_dense_ = wf_dense_;
-        resident_flow_ = flow;
+        resident_variant_ = variant;
     }
-    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, flow, stream_), "render");
+    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, variant, stream_), "render");
     queue_parity_ ^= 1u;
 }
 

@@ -94,7 +94,8 @@ private:
     cpt::WavefrontBuffers wf_{};
     int wf_resident_blocks_ = 0, wf_finish_blocks_ = 0;
     bool wf_dense_ = false;          // set by BuildBuffers from the scene's triangle count: which build of the persistent kernels runs
-    bool resident_dense_ = false, resident_flow_ = false;
+    bool resident_dense_ = false;
+    int resident_variant_ = 0;
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 

@@ -17,9 +17,10 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
 // 0,1,0,.. on one stream after zeroing everything once).  max_blocks: render_regen_resident_blocks() of the device.
 // dense: the build with more waves per SIMD and a shorter LDS stack, for scenes whose BVH does not fit the vector L1.
 constexpr uint32_t kRegenQueueWords = 2 * kCursorSetWords;
-// flow: the build that keeps traversal state across shading and re-enters the loop with partly finished waves (k_render_flow).
-int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, bool flow, hipStream_t stream);
-int render_regen_resident_blocks(int device, bool dense, bool flow);
+// variant: 0 = k_render_regen; 1 = the build that keeps traversal state across shading and re-enters the loop with partly
+// finished waves (k_render_flow); 2 = the build whose finished lanes walk the wave's pooled shadow rays (k_render_pool).
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream);
+int render_regen_resident_blocks(int device, bool dense, int variant);
 
 // Compares the traversal's reciprocal-based exact division with the hardware division on at least
 // `pairs` operand pairs; adds the number of differing results to *d_mismatches (device memory).

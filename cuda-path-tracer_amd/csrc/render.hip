@@ -262,12 +262,144 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
         // code into nearly every trip for one or two lanes, so it runs every sixteenth trip and when nothing moves.
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = s.has_shadow;
-            const bool moved = t.step(sc, st, cnt, s.l.ro, shadow ? s.shadow_dir : s.l.rd, shadow);
+            const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) { ow = s.l.ro; dw = shadow ? s.shadow_dir : s.l.rd; }, shadow);
             if (moved && (trip & 15u) != 15u) continue;
             if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
             const int waiting = lanes_in(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));
             if (walking == 0 || (waiting > 0 && waiting * 8 >= (walking + waiting) * kFlowShadeEighths)) break;
+        }
+    }
+    flush_counters(sc, cnt, paths, s_cnt);
+}
+
+// The lane-regenerating kernel with its shadow rays pooled per wave.  Measured with a probe build on
+// cornell-box-glass, 72 % of the lane slots of k_render_regen's traversal trips belong to lanes whose ray
+// is already finished (5 % to lanes that lost the vote): every trace call lasts as long as its longest
+// ray.  Here the wave still shades all its lanes together, once per bounce, but the shadow rays that
+// shading produces go to a list in LDS, and in the next traversal loop a lane whose own extension ray is
+// finished takes shadow rays from that list (any lane's), so they fill the slots that would idle and the
+// separate shadow trace disappears.  The owner adds its light contribution when the next shading step
+// finds its ray marked as having reached the light: same order of additions per path as before.
+template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 9 : 12; };
+#ifndef POOL_MASK
+#define POOL_MASK 3u
+#endif
+constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every fourth trip
+
+template <bool MAPS, bool DENSE>
+__global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
+    __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    __shared__ float4 s_pool[3 * kTraceBlock];       // per wave 64 shadow rays: (origin, reach), (direction, owner lane | fast-division flag << 8), (1 / direction, -)
+    __shared__ uint32_t s_lit[kTraceBlock];          // per owner lane: its shadow ray reached the light
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<PoolShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
+    LaneCounters cnt;
+    uint32_t paths = 0;
+    const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    uint32_t *cursors = queue + parity * kCursorSetWords;
+    zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
+
+    SegmentFetchT<false> fetch;
+    FlowLane s;
+    Flow t;
+    bool ext_found = false;                 // result of the lane's own extension ray, kept while it walks other lanes' shadow rays
+    Hit ext_hit{0u, 0u, 0.0f, 0.0f};
+    uint32_t job = 0xffffffffu;             // slot of the shadow ray the lane walks, in its wave's list
+    uint32_t pool_count = 0;                // wave-uniform: shadow rays in the list
+
+    for (;;) {
+        // ---- hand new pixels to idle lanes
+        unsigned long long idle = __ballot(!s.l.alive);
+        while (idle != 0ull && !fetch.exhausted) {
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            const uint32_t rank = __popcll(idle & lt_mask);
+            const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
+            const uint32_t slot = fetch.entry(rank);
+            if (!s.l.alive && rank < take) {
+                const uint32_t tile = slot >> 6, k = slot & 63u;
+                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                if (px < p.width && py < p.height) {
+                    PathLane &l = s.l;
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
+                    l.alive = true; l.primary = true; l.last_specular = false;
+                    l.depth = 0; l.color = v3(0.0f); l.throughput = v3(1.0f);
+                    s.has_ext = true; s.has_shadow = false;
+                    paths++;
+                }
+            }
+            fetch.consumed += take;
+            idle = __ballot(!s.l.alive);
+        }
+        if (__ballot(s.l.alive) == 0ull) break;        // nothing in flight and every tile is handed out
+
+        // ---- every lane begins its own extension ray
+        job = 0xffffffffu;
+        s.ext_traced = s.l.alive && s.has_ext;
+        t = Flow();                                     // nothing of the last bounce's walks is carried over
+        if (s.ext_traced) t.begin(sc, s.l.ro, s.l.rd, kRayTMax, Flow::prepare(sc, s.l.ro, s.l.rd, kRayTMax), cnt);
+        bool own = s.ext_traced;                        // the ray in `t` is the lane's own extension ray
+        uint32_t pool_next = 0;
+
+        // ---- walk; lanes without a ray take shadow rays from the list
+        for (uint32_t trip = 0;; trip++) {
+            const bool shadow = !own;
+            const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) {
+                if (own) { ow = s.l.ro; dw = s.l.rd; }
+                else { float4 a = s_pool[3 * (wave_base + job)], b = s_pool[3 * (wave_base + job) + 1]; ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
+            }, shadow);
+            if (moved && (trip & kPoolPeriodMask) != kPoolPeriodMask) continue;
+            const bool free_lane = !t.walking();
+            if (free_lane && own) { ext_found = t.found; ext_hit = t.hit; own = false; }
+            if (free_lane && job != 0xffffffffu) {
+                if (!t.found) s_lit[wave_base + (__float_as_uint(s_pool[3 * (wave_base + job) + 1].w) & 63u)] = 1u;
+                job = 0xffffffffu;
+            }
+            const unsigned long long free_mask = __ballot(free_lane);
+            const uint32_t avail = pool_count - pool_next, rank = __popcll(free_mask & lt_mask);
+            if (free_lane && rank < avail) {
+                job = pool_next + rank;
+                const float4 a = s_pool[3 * (wave_base + job)], b = s_pool[3 * (wave_base + job) + 1], c = s_pool[3 * (wave_base + job) + 2];
+                Flow::Prepared q;
+                q.r = v3(c.x, c.y, c.z);
+                q.fast = (__float_as_uint(b.w) >> 8) & 1u;
+                q.enters = true;                        // rays that miss the scene's box are not listed
+                t.begin(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, q, cnt, false);      // counted when it was listed
+            }
+            pool_next += min((uint32_t)__popcll(free_mask), avail);
+            if (__ballot(t.walking()) == 0ull && pool_next == pool_count) break;
+        }
+
+        // ---- shade: last bounce's light contribution first, then this bounce's hit
+        if (s.l.alive) {
+            if (s.has_shadow) {
+                if (s_lit[threadIdx.x]) s.l.color = s.l.color + s.pending;
+                s.has_shadow = false;
+            }
+            Flow result;
+            result.found = ext_found;
+            result.hit = ext_hit;
+            flow_shade<MAPS>(sc, p, s, result, cnt);
+        }
+        // the shadow rays of this bounce, packed at the front of the wave's list with what a lane needs to begin
+        // them; one that misses the scene's box has nothing between the point and the light
+        Flow::Prepared listed{v3(0.0f), false, false};
+        if (s.l.alive && s.has_shadow) {
+            listed = Flow::prepare(sc, s.l.ro, s.shadow_dir, s.shadow_tmax);
+            cnt.rays++;
+            if (!listed.enters) { s.l.color = s.l.color + s.pending; s.has_shadow = false; }
+        }
+        const unsigned long long with_shadow = __ballot(s.l.alive && s.has_shadow);
+        pool_count = __popcll(with_shadow);
+        if (s.l.alive && s.has_shadow) {
+            const uint32_t e = wave_base + __popcll(with_shadow & lt_mask);
+            s_pool[3 * e] = make_float4(s.l.ro.x, s.l.ro.y, s.l.ro.z, s.shadow_tmax);
+            s_pool[3 * e + 1] = make_float4(s.shadow_dir.x, s.shadow_dir.y, s.shadow_dir.z, __uint_as_float(lane | (listed.fast ? 256u : 0u)));
+            s_pool[3 * e + 2] = make_float4(listed.r.x, listed.r.y, listed.r.z, 0.0f);
+            s_lit[threadIdx.x] = 0u;
         }
     }
     flush_counters(sc, cnt, paths, s_cnt);
@@ -400,13 +532,23 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
-int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, bool flow, hipStream_t stream) {
+int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream) {
     uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
     if (tiles == 0) return 0;
     uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? want : max_blocks;
     const dim3 grid(blocks), block(kTraceBlock);
-    if (flow) {
+    if (variant == 2) {
+        if (sc.textures) {
+            if (dense) hipLaunchKernelGGL((k_render_pool<true, true>), grid, block, 0, stream, sc, p, queue, parity);
+            else hipLaunchKernelGGL((k_render_pool<true, false>), grid, block, 0, stream, sc, p, queue, parity);
+        } else {
+            if (dense) hipLaunchKernelGGL((k_render_pool<false, true>), grid, block, 0, stream, sc, p, queue, parity);
+            else hipLaunchKernelGGL((k_render_pool<false, false>), grid, block, 0, stream, sc, p, queue, parity);
+        }
+        return (int)hipGetLastError();
+    }
+    if (variant == 1) {
         if (sc.textures) hipLaunchKernelGGL(k_render_flow<true>, grid, block, 0, stream, sc, p, queue, parity);
         else hipLaunchKernelGGL(k_render_flow<false>, grid, block, 0, stream, sc, p, queue, parity);
         return (int)hipGetLastError();
@@ -421,13 +563,16 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device, bool dense, bool flow) {
+int render_regen_resident_blocks(int device, bool dense, int variant) {
     int per_cu = 0, other = 0, cus = 0;
     const void *with_maps = dense ? (const void *)k_render_regen<true, true> : (const void *)k_render_regen<true, false>;
     const void *without = dense ? (const void *)k_render_regen<false, true> : (const void *)k_render_regen<false, false>;
-    if (flow) {
+    if (variant == 1) {
         with_maps = (const void *)k_render_flow<true>;
         without = (const void *)k_render_flow<false>;
+    } else if (variant == 2) {
+        with_maps = dense ? (const void *)k_render_pool<true, true> : (const void *)k_render_pool<true, false>;
+        without = dense ? (const void *)k_render_pool<false, true> : (const void *)k_render_pool<false, false>;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_maps, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, without, kTraceBlock, 0) != hipSuccess || other < 1) other = 1;

@@ -103,14 +103,14 @@ def test_material_maps_render_like_the_oracle(cpt, tmp_path, bsdf):
     sc = cpt.Scene().load_obj(obj, bsdf)
     sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], 64, 64)
     imgs = []
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 5):
         tr = cpt.Tracer(sc, 64, 64, max_depth=5).build_buffers()
         tr.set_integrator(mode)
         tr.update(16)
         imgs.append(tr.film())
     ref, _ = osc.render(64, 64, 1, 17, 5)
     compare(imgs[0], ref)
-    for k in (1, 2, 3):
+    for k in (1, 2, 3, 4):
         assert np.array_equal(imgs[0].view(np.uint32), imgs[k].view(np.uint32)), k
     plain = [dict(o) for o in objs]
     for o in plain:
@@ -201,7 +201,7 @@ def test_large_scene_builds_of_the_integrators_agree(cpt, kind, depth):
     the plain persistent kernel (0) and the ray queues (2), and close to the oracle."""
     objs, cam = synthetic_scene(kind, 70000)
     imgs, rays = [], []
-    for mode in (0, 2, 3, 4):
+    for mode in (0, 2, 3, 4, 5):
         sc, tr = gpu_scene(cpt, objs, cam, 100, 60, max_depth=depth)
         tr.set_integrator(mode)
         tr.update(4)
@@ -263,7 +263,7 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
     must be identical, not merely close; so must their ray counts."""
     objs, cam = cornell(glass=True)
     imgs, rays = [], []
-    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1), (3, None), (4, None)):
+    for mode, tail in ((0, None), (1, None), (2, None), (2, -1), (2, 0), (2, 1), (3, None), (4, None), (5, None)):
         sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=depth)     # not a multiple of the 8x8 tiles
         tr.set_integrator(mode)
         if tail is not None:
@@ -281,7 +281,7 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
 def test_wavefront_sum_mode_and_normal_channel(cpt):
     objs, cam = cornell(glass=False)
     out = []
-    for mode in (0, 2, 4):
+    for mode in (0, 2, 4, 5):
         sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=4)
         tr.set_integrator(mode)
         buf = cpt.DeviceArray((64, 64, 4), np.float32); buf.zero()
@@ -291,6 +291,6 @@ def test_wavefront_sum_mode_and_normal_channel(cpt):
         tr.set_channel(1)
         tr.update(1)
         out.append((a, tr.film()))
-    for k in (1, 2):
+    for k in (1, 2, 3):
         assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
         assert np.array_equal(out[0][1].view(np.uint32), out[k][1].view(np.uint32))
