@@ -107,8 +107,8 @@ def main():
     ap.add_argument("--workload", default="cornell-box-glass",
                     help="cornell-box-glass (the metric's configuration, default) or a synthetic scene: heightfield-1m, heightfield-10m, soup-1m, soup-10m")
     ap.add_argument("--integrator", type=int, default=3,
-                    help="3 by scene size (default: 0 for the Cornell box, 4 for the synthetic scenes), 0 persistent megakernel, 1 megakernel, "
-                         "2 wavefront, 4 persistent megakernel that shades partly finished waves")
+                    help="3 by scene size (default: 5 for the Cornell box, 4 for the synthetic scenes), 0 persistent megakernel, 1 megakernel, "
+                         "2 wavefront, 4 persistent megakernel that shades partly finished waves, 5 persistent megakernel with pooled shadow rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -157,10 +157,11 @@ def main():
     tracer = cpt.Tracer(scene, W, H, max_depth=args.max_depth)
     tracer.set_integrator(args.integrator)
     tracer.build_buffers()
-    integrator = args.integrator if args.integrator != 3 else (4 if scene_triangles >= 65536 else 0)     # what mode 3 resolves to in the library
-    kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow"}[integrator]
+    integrator = args.integrator if args.integrator != 3 else (4 if scene_triangles >= 65536 else 5)     # what mode 3 resolves to in the library
+    kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow", 5: "k_render_pool"}[integrator]
     integrator_name = {0: "persistent megakernel (lane regeneration)", 1: "megakernel, one lane per pixel", 2: "wavefront (ray queues) + persistent tail",
-                       4: "persistent megakernel, traversal state kept across shading"}[integrator]
+                       4: "persistent megakernel, traversal state kept across shading",
+                       5: "persistent megakernel, finished lanes walk the wave's pooled shadow rays"}[integrator]
 
     def barrier():
         if world > 1:
@@ -244,9 +245,10 @@ def main():
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and args.workload == "cornell-box-glass" and integrator == 0 and (W, H, args.max_depth) == (1024, 1024, 8):
+            if os.path.exists(tpath) and args.workload == "cornell-box-glass" and (W, H, args.max_depth) == (1024, 1024, 8):
                 try:
-                    traffic = json.load(open(tpath)).get("k_render_regen_hbm_bytes_per_launch")
+                    measured = json.load(open(tpath))
+                    traffic = measured.get("hbm_bytes_per_launch") if measured.get("kernel") == kernel_name else None
                 except Exception:
                     traffic = None
             result["roofline"] = {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

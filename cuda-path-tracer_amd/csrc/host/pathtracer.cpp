@@ -316,10 +316,10 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
 }
 
 void PathTracer::LaunchSample(const cpt::RenderParams &p) {
-    // 3 = by scene size: the persistent kernel that shades partly finished waves (4) is ahead of both the plain
-    // persistent kernel and the ray queues once rays are long (measured at 1M and 10M triangles), and behind the
-    // plain one on a scene as small as the Cornell box
-    const int integrator = integrator_ == 3 ? (wf_dense_ ? 4 : 0) : integrator_;
+    // 3 = by scene size: the persistent kernel that shades partly finished waves (4) is ahead of every other once
+    // rays are long (measured at 1M and 10M triangles); on a scene as small as the Cornell box the one that shades
+    // whole waves and lets finished lanes walk the pooled shadow rays (5) is
+    const int integrator = integrator_ == 3 ? (wf_dense_ ? 4 : 5) : integrator_;
     if (integrator == 2) {
         LaunchWavefront(p);
         return;

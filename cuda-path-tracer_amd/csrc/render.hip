@@ -283,9 +283,9 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 // finds its ray marked as having reached the light: same order of additions per path as before.
 template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 9 : 12; };
 #ifndef POOL_MASK
-#define POOL_MASK 3u
+#define POOL_MASK 7u
 #endif
-constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every fourth trip
+constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every eighth trip
 
 template <bool MAPS, bool DENSE>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
