@@ -138,8 +138,10 @@ struct FlowLane {
 // Shading for the lanes whose extension ray is finished (or whose path has nothing left to trace):
 // the part of Trace between two traversals (path.cu:13-55 for the first hit, :57-80 + :27-55 later).
 // Leaves the lane either ended (film written, l.alive false) or with has_shadow / has_ext set.
-template <bool MAPS>
-__device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, FlowLane &s, const Flow &t, LaneCounters &cnt) {
+// emit(pos, dir, reach, contribution) is called for the shadow ray of this path vertex, if there is one, before
+// the BSDF is sampled; it returns whether the ray has to be traced (false: the caller has dealt with it).
+template <bool MAPS, class Emit>
+__device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, FlowLane &s, const Flow &t, LaneCounters &cnt, Emit emit) {
     PathLane &l = s.l;
     bool finish = !s.ext_traced || !t.found;
     if (!finish) {
@@ -179,10 +181,7 @@ __device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, Flo
                     V3 wi = frame.to_local(ls.dir);
                     float bp = bsdf_pdf(surface.bsdf, wo, wi);
                     float mis_weight = power_heuristic(ls.pdf, bp);
-                    s.pending = l.throughput * mis_weight * ls.weight * bsdf_eval(surface.bsdf, wo, wi);
-                    s.shadow_dir = ls.dir;
-                    s.shadow_tmax = ls.dist - kShadowRayEps;
-                    s.has_shadow = true;
+                    s.has_shadow = emit(pos, ls.dir, ls.dist - kShadowRayEps, l.throughput * mis_weight * ls.weight * bsdf_eval(surface.bsdf, wo, wi));
                 }
             }
             float b1 = l.sampler.next1d();

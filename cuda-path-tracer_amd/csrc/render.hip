@@ -200,7 +200,11 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 
     for (;;) {
         // ---- shade the lanes whose extension ray is done
-        if (s.l.alive && !t.walking()) flow_shade<MAPS>(sc, p, s, t, cnt);
+        if (s.l.alive && !t.walking())
+            flow_shade<MAPS>(sc, p, s, t, cnt, [&](V3, V3 dir, float reach, V3 contribution) {
+                s.shadow_dir = dir; s.shadow_tmax = reach; s.pending = contribution;
+                return true;
+            });
 
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 // finished takes shadow rays from that list (any lane's), so they fill the slots that would idle and the
 // separate shadow trace disappears.  The owner adds its light contribution when the next shading step
 // finds its ray marked as having reached the light: same order of additions per path as before.
-template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 9 : 12; };
+template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 7 : 11; };
 #ifndef POOL_MASK
 #define POOL_MASK 7u
 #endif
@@ -291,8 +295,9 @@ template <bool MAPS, bool DENSE>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    __shared__ float4 s_pool[3 * kTraceBlock];       // per wave 64 shadow rays: (origin, reach), (direction, owner lane | fast-division flag << 8), (1 / direction, -)
-    __shared__ uint32_t s_lit[kTraceBlock];          // per owner lane: its shadow ray reached the light
+    // the shadow ray of each lane's path: (origin, reach), (direction, fast-division flag), (1 / direction, -), (light contribution, reached the light)
+    __shared__ float4 s_pool[4 * kTraceBlock];
+    __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
     TraceStackT<PoolShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
     LaneCounters cnt;
@@ -345,27 +350,28 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         uint32_t pool_next = 0;
 
         // ---- walk; lanes without a ray take shadow rays from the list
+        float *const pool_words = reinterpret_cast<float *>(s_pool);
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = !own;
             const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) {
                 if (own) { ow = s.l.ro; dw = s.l.rd; }
-                else { float4 a = s_pool[3 * (wave_base + job)], b = s_pool[3 * (wave_base + job) + 1]; ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
+                else { float4 a = s_pool[4 * (wave_base + job)], b = s_pool[4 * (wave_base + job) + 1]; ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
             }, shadow);
             if (moved && (trip & kPoolPeriodMask) != kPoolPeriodMask) continue;
             const bool free_lane = !t.walking();
             if (free_lane && own) { ext_found = t.found; ext_hit = t.hit; own = false; }
             if (free_lane && job != 0xffffffffu) {
-                if (!t.found) s_lit[wave_base + (__float_as_uint(s_pool[3 * (wave_base + job) + 1].w) & 63u)] = 1u;
+                if (!t.found) pool_words[16 * (wave_base + job) + 15] = 1.0f;      // reached the light
                 job = 0xffffffffu;
             }
             const unsigned long long free_mask = __ballot(free_lane);
             const uint32_t avail = pool_count - pool_next, rank = __popcll(free_mask & lt_mask);
             if (free_lane && rank < avail) {
-                job = pool_next + rank;
-                const float4 a = s_pool[3 * (wave_base + job)], b = s_pool[3 * (wave_base + job) + 1], c = s_pool[3 * (wave_base + job) + 2];
+                job = s_order[wave_base + pool_next + rank];
+                const float4 a = s_pool[4 * (wave_base + job)], b = s_pool[4 * (wave_base + job) + 1], c = s_pool[4 * (wave_base + job) + 2];
                 Flow::Prepared q;
                 q.r = v3(c.x, c.y, c.z);
-                q.fast = (__float_as_uint(b.w) >> 8) & 1u;
+                q.fast = __float_as_uint(b.w) != 0u;
                 q.enters = true;                        // rays that miss the scene's box are not listed
                 t.begin(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, q, cnt, false);      // counted when it was listed
             }
@@ -373,34 +379,32 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
             if (__ballot(t.walking()) == 0ull && pool_next == pool_count) break;
         }
 
-        // ---- shade: last bounce's light contribution first, then this bounce's hit
+        // ---- shade: last bounce's light contribution first, then this bounce's hit.  The shadow ray goes to the
+        // lane's slot of the list as soon as it is known, with what another lane needs to begin it; one that misses
+        // the scene's box has nothing between the point and the light.
         if (s.l.alive) {
             if (s.has_shadow) {
-                if (s_lit[threadIdx.x]) s.l.color = s.l.color + s.pending;
+                const float4 c = s_pool[4 * threadIdx.x + 3];
+                if (c.w != 0.0f) s.l.color = s.l.color + v3(c.x, c.y, c.z);
                 s.has_shadow = false;
             }
             Flow result;
             result.found = ext_found;
             result.hit = ext_hit;
-            flow_shade<MAPS>(sc, p, s, result, cnt);
-        }
-        // the shadow rays of this bounce, packed at the front of the wave's list with what a lane needs to begin
-        // them; one that misses the scene's box has nothing between the point and the light
-        Flow::Prepared listed{v3(0.0f), false, false};
-        if (s.l.alive && s.has_shadow) {
-            listed = Flow::prepare(sc, s.l.ro, s.shadow_dir, s.shadow_tmax);
-            cnt.rays++;
-            if (!listed.enters) { s.l.color = s.l.color + s.pending; s.has_shadow = false; }
+            flow_shade<MAPS>(sc, p, s, result, cnt, [&](V3 pos, V3 dir, float reach, V3 contribution) {
+                const Flow::Prepared q = Flow::prepare(sc, pos, dir, reach);
+                cnt.rays++;
+                if (!q.enters) { s.l.color = s.l.color + contribution; return false; }
+                s_pool[4 * threadIdx.x] = make_float4(pos.x, pos.y, pos.z, reach);
+                s_pool[4 * threadIdx.x + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(q.fast ? 1u : 0u));
+                s_pool[4 * threadIdx.x + 2] = make_float4(q.r.x, q.r.y, q.r.z, 0.0f);
+                s_pool[4 * threadIdx.x + 3] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                return true;
+            });
         }
         const unsigned long long with_shadow = __ballot(s.l.alive && s.has_shadow);
         pool_count = __popcll(with_shadow);
-        if (s.l.alive && s.has_shadow) {
-            const uint32_t e = wave_base + __popcll(with_shadow & lt_mask);
-            s_pool[3 * e] = make_float4(s.l.ro.x, s.l.ro.y, s.l.ro.z, s.shadow_tmax);
-            s_pool[3 * e + 1] = make_float4(s.shadow_dir.x, s.shadow_dir.y, s.shadow_dir.z, __uint_as_float(lane | (listed.fast ? 256u : 0u)));
-            s_pool[3 * e + 2] = make_float4(listed.r.x, listed.r.y, listed.r.z, 0.0f);
-            s_lit[threadIdx.x] = 0u;
-        }
+        if (s.l.alive && s.has_shadow) s_order[wave_base + __popcll(with_shadow & lt_mask)] = (uint8_t)lane;
     }
     flush_counters(sc, cnt, paths, s_cnt);
 }
