@@ -119,6 +119,7 @@ struct SceneDev {
     float light_pick_pdf;
     CameraDev camera;
     Counters *counters;         // kCounterSlots slots; may be null
+    int large_scene;            // the BVH is far larger than the caches next to the CUs: batch queries use the kernel builds for such scenes
 };
 
 struct RenderParams {

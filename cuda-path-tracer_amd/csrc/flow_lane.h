@@ -64,7 +64,7 @@ struct Flow {
         const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
         const int cn = lanes_in(__ballot(is_node)), ct = lanes_in(__ballot(is_tri)), ci = lanes_in(__ballot(is_inst));
         bool need_pop = false;
-        if (cn >= ct && cn >= ci) {
+        if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
             if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);

@@ -50,6 +50,7 @@ void PathTracer::BuildBuffers() {
     scene_triangles_ = triangles;
     const bool dense = triangles >= 65536;
     if (dense != wf_dense_) { wf_dense_ = dense; wf_.capacity = 0; }      // the resident workgroup count is looked up again
+    scene_dev_.large_scene = dense ? 1 : 0;
     CPT_HIP(hipStreamSynchronize(stream_));
     built_ = true;
 }

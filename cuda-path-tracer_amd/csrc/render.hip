@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
     __shared__ uint2 s_stack[RegenShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<RegenShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
+    TraceStackT<RegenShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
     __shared__ unsigned long long s_cnt[5];
     __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kLdsStackEntries> st(s_stack, spill_entries);
+    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene> st(s_stack, spill_entries);      // the build for large scenes
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     __shared__ float4 s_pool[4 * kTraceBlock];
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<PoolShape<DENSE>::kLdsEntries> st(s_stack, spill_entries);
+    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
@@ -414,12 +414,13 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
 constexpr int kQueryWaves = 8;
 constexpr int kQueryLdsEntries = 8;
 
+template <bool LARGE>
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -436,11 +437,12 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
+template <bool LARGE>
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -589,7 +591,8 @@ int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_first_hit, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
+    if (sc.large_scene) hipLaunchKernelGGL(k_first_hit<true>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
+    else hipLaunchKernelGGL(k_first_hit<false>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
     return (int)hipGetLastError();
 }
 
@@ -597,7 +600,8 @@ int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *o
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_occlude, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
+    if (sc.large_scene) hipLaunchKernelGGL(k_occlude<true>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
+    else hipLaunchKernelGGL(k_occlude<false>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
     return (int)hipGetLastError();
 }
 

@@ -40,9 +40,12 @@ __device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return mak
 // LDS_ENTRIES is a kernel's trade between LDS per workgroup (occupancy) and how deep a tree goes
 // before entries land in private memory.  The two arrays live in the kernel (a __shared__ array of
 // LDS_ENTRIES * kTraceBlock entries and a local array of kSpillEntries); this holds their addresses.
-template <int LDS_ENTRIES>
+// LEAF_WEIGHT rides along because it is, like the stack's shape, a choice each kernel build makes for the
+// scenes it is meant for (see Traversal::vote_step).
+template <int LDS_ENTRIES, int LEAF_WEIGHT = 1>
 struct TraceStackT {
     static constexpr int kLdsEntries = LDS_ENTRIES;
+    static constexpr int kLeafWeight = LEAF_WEIGHT;
     LdsStack lds;
     PrivateStack spill;
     __device__ inline TraceStackT(uint2 *shared_entries, uint2 *private_entries)
@@ -155,6 +158,13 @@ __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, fl
 
 constexpr uint32_t kNoNode = 0xffffffffu;
 
+// The wave runs the kind of step that has the most lanes, with lanes at a triangle or at an instance counted
+// Stack::kLeafWeight times: those are the rarer kinds, and a lane that waits at one until its kind outnumbers
+// the node walkers holds its ray back for many trips.  Measured with the weights 1, 2, 3, 4, 8: on scenes whose
+// rays diverge 4 is best (soup 1M 102 -> 126 Mpaths/s, heightfield 10M 396 -> 428), on the Cornell box and on
+// coherent camera rays 1 is (4 costs 2-4 % there), so the kernel builds for large scenes use 4, the others 1.
+constexpr int kLeafWeightLargeScene = 4;
+
 // Traversal state of one lane: where it stands (`cur`: internal node, triangle slot, instance
 // leaf, or kNoNode when the ray is finished), its stack window and the ray in world and instance
 // space.  Closest hit (ANY = false) is AccelTop::Intersect (accel.cuh:124-150), any hit
@@ -203,7 +213,7 @@ struct Traversal {
         if ((mn | mt | mi) == 0ull) return false;
         const int cn = lanes_in(mn), ct = lanes_in(mt), ci = lanes_in(mi);
         bool need_pop = false;
-        if (cn >= ct && cn >= ci) {
+        if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
             if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
