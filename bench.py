@@ -100,7 +100,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--max-depth", type=int, default=8)
@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--integrator", type=int, default=3,
                     help="3 by scene size (default: 5 for the Cornell box, 4 for the synthetic scenes), 0 persistent megakernel, 1 megakernel, "
                          "2 wavefront, 4 persistent megakernel that shades partly finished waves, 5 persistent megakernel with pooled shadow rays")
+    ap.add_argument("--samples-per-launch", type=int, default=32,
+                    help="samples (steps) the persistent kernels of integrators 4 and 5 render per launch; the film is bit for bit "
+                         "that of one launch per sample (1 = one launch per sample, as the reference launches RenderKernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -156,6 +159,7 @@ def main():
         scene_triangles = sum(len(o["indices"]) // 3 for o in objs)
     tracer = cpt.Tracer(scene, W, H, max_depth=args.max_depth)
     tracer.set_integrator(args.integrator)
+    tracer.set_samples_per_launch(args.samples_per_launch)
     tracer.build_buffers()
     integrator = args.integrator if args.integrator != 3 else (4 if scene_triangles >= 65536 else 5)     # what mode 3 resolves to in the library
     kernel_name = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow", 5: "k_render_pool"}[integrator]
@@ -235,13 +239,18 @@ def main():
             "data": "reference scene file cornell-box-glass (committed fixture); synthetic soups for the LBVH timings"
                     if args.workload == "cornell-box-glass" else "synthetic scene from a seeded generator (tests/helpers.py); synthetic soups for the LBVH timings",
             "config": {"workload": f"{workload}, 1 spp per step, {K} spp per GPU",
+                       "samples_per_launch": args.samples_per_launch if integrator in (4, 5) else 1,
                        "integrator": integrator_name, "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks + 1 sum-reduce"},
             "mrays_per_s": round(total["rays"] / elapsed / 1e6, 3),
             "rays_per_path": round(total["rays"] / max(total["paths"], 1), 4),
         }
         if kernel_ms is not None:
-            per_launch_bytes = algorithmic_bytes(counters, W * H, K)     # rank 0's own launches
-            avg_ms = kernel_ms / K
+            # rank 0's own launches: K samples in launches of samples_per_launch (the last one may be shorter)
+            own = K if world == 1 else sharding.sample_block(rank, world, K)[1]
+            per_launch = args.samples_per_launch if integrator in (4, 5) else 1
+            launches = -(-own // per_launch)
+            per_launch_bytes = algorithmic_bytes(counters, W * H, own) * own / launches
+            avg_ms = kernel_ms / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -253,7 +262,8 @@ def main():
                     traffic = None
             result["roofline"] = {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                  "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+                                  "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                                  "samples_per_launch": per_launch, "launches": launches}
         if world == 1 and not args.no_lbvh:
             result["lbvh"] = {"1M": lbvh_timings(cpt, 1_000_000), "10M": lbvh_timings(cpt, 10_000_000)}
             # what a kernel that only streams reaches on this device (1 GiB copied, read + written bytes counted),

@@ -75,6 +75,8 @@ _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
 _sig("cpt_tracer_update", C.c_int, [_vp])
 _sig("cpt_tracer_update_timed", C.c_int, [_vp, C.c_uint32, _vp])
+_sig("cpt_tracer_update_many", C.c_int, [_vp, C.c_uint32])
+_sig("cpt_tracer_set_samples_per_launch", C.c_int, [_vp, C.c_uint32])
 _sig("cpt_tracer_timer_begin", C.c_int, [_vp])
 _sig("cpt_tracer_timer_end", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_accumulation", C.c_int, [_vp])
@@ -318,8 +320,14 @@ class Tracer:
         return self
 
     def update(self, n=1):
-        for _ in range(n):
+        """n more samples per pixel (cpt_tracer_update_many: same film as n single updates)."""
+        if n == 1:
             check(lib.cpt_tracer_update(self.h))
+        else:
+            check(lib.cpt_tracer_update_many(self.h, n))
+
+    def set_samples_per_launch(self, samples):
+        check(lib.cpt_tracer_set_samples_per_launch(self.h, samples))
 
     def update_timed(self, n):
         """n Update calls; returns the device milliseconds measured on the tracer's stream."""

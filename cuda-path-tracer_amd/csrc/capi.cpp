@@ -434,6 +434,16 @@ int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bb
     return rc == CPT_OK ? (int64_t)v.num_primitives : rc;
 }
 
+int cpt_tracer_update_many(cpt_tracer *t, uint32_t count) {
+    TRACER_OR_FAIL(t);
+    return Guard([&] { t->tracer->UpdateMany(count); return CPT_OK; });
+}
+int cpt_tracer_set_samples_per_launch(cpt_tracer *t, uint32_t samples) {
+    TRACER_OR_FAIL(t);
+    if (samples < 1 || samples > 64) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_samples_per_launch: 1 to 64");
+    t->tracer->SetSamplesPerLaunch(samples);
+    return CPT_OK;
+}
 int cpt_tracer_update_timed(cpt_tracer *t, uint32_t count, float *elapsed_ms) {
     TRACER_OR_FAIL(t);
     if (!elapsed_ms) return Fail(CPT_ERR_INVALID, "cpt_tracer_update_timed: null argument");

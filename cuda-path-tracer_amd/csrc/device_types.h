@@ -129,6 +129,11 @@ struct RenderParams {
     uint32_t max_depth;         // 0xffffffff = unbounded
     int channel;                // 0 colour, 1 normal
     int sum_mode;               // 0: running mean (reference semantics); 1: plain sum (sharded renders)
+    // Several samples in one launch (the persistent kernels that take it): samples spp .. spp + spp_count - 1 of
+    // every pixel.  `order` then holds one word per pixel, zero at launch: the number of this launch's samples the
+    // pixel has received, which is what keeps a pixel's samples arriving in sample order.
+    uint32_t spp_count = 1;
+    uint32_t *order = nullptr;
 };
 
 }  // namespace cpt

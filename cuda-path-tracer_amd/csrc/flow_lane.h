@@ -143,7 +143,7 @@ struct FlowLane {
 template <bool MAPS, class Emit>
 __device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, FlowLane &s, const Flow &t, LaneCounters &cnt, Emit emit) {
     PathLane &l = s.l;
-    bool finish = !s.ext_traced || !t.found;
+    bool finish = l.film_pending || !s.ext_traced || !t.found;
     if (!finish) {
         Surface surface = shading_surface<MAPS>(sc, t.hit, cnt);
         if (l.primary) {
@@ -200,11 +200,16 @@ __device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, Flo
         }
     }
     if (finish) {
-        film_accumulate(p, l.pixel_index, l.color);
-        l.alive = false;
         s.has_shadow = false;
         s.has_ext = false;
         s.ext_traced = false;
+        if (p.order) {
+            l.film_pending = !film_accumulate_in_order(p, l.pixel_index, l.pass, l.color);
+            l.alive = l.film_pending;
+        } else {
+            film_accumulate(p, l.pixel_index, l.color);
+            l.alive = false;
+        }
     }
 }
 

@@ -1,5 +1,6 @@
 #include "pathtracer.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -270,6 +271,53 @@ void PathTracer::Update() {
     film_.DeviceUnmap();
 }
 
+// `count` times Update(), with the launches of several samples folded into one where the kernel in use can do
+// that: a launch's start and the tail of its longest paths cost about as much as a third of a 1024 x 1024 sample.
+void PathTracer::UpdateMany(uint32_t count) {
+    if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty() || count == 0) return;
+    if (film_.Width() != last_width_ || film_.Height() != last_height_) {
+        ResetAccumelation();
+        last_width_ = film_.Width();
+        last_height_ = film_.Height();
+    }
+    cpt::RenderParams p;
+    p.output = film_.DeviceMap(stream_);
+    p.width = film_.Width();
+    p.height = film_.Height();
+    p.spp = curr_spp_ + 1;
+    p.max_depth = static_cast<uint32_t>(max_depth_);
+    p.channel = display_channel_;
+    p.sum_mode = 0;
+    LaunchSamples(p, count);
+    curr_spp_ += count;
+    film_.DeviceUnmap();
+}
+
+void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
+    const int integrator = integrator_ == 3 ? (wf_dense_ ? 4 : 5) : integrator_;
+    const bool folds = (integrator == 4 || integrator == 5) && samples_per_launch_ > 1;
+    while (count != 0) {
+        uint32_t batch = 1;
+        if (folds && count > 1) {
+            const unsigned long long tiles = (unsigned long long)((p.width + 7) / 8) * ((p.height + 7) / 8);
+            const unsigned long long fits = tiles ? 0xffffffffull / (tiles * cpt::kSegmentSlots) : 1;       // slot numbers are 32 bits
+            batch = (uint32_t)std::min<unsigned long long>({(unsigned long long)count, (unsigned long long)samples_per_launch_, fits ? fits : 1});
+        }
+        if (batch > 1) {
+            const size_t words = (size_t)p.width * p.height;
+            if (order_.Size() != words * sizeof(uint32_t)) order_.Allocate(words * sizeof(uint32_t));
+            order_.Zero(stream_);
+            p.order = order_.TypedGpuData<uint32_t>();
+        } else {
+            p.order = nullptr;
+        }
+        p.spp_count = batch;
+        LaunchSample(p);
+        p.spp += batch;
+        count -= batch;
+    }
+}
+
 void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
     size_t slots = cpt::wavefront_slots(p.width, p.height);
     if (wf_.capacity != slots) {
@@ -353,10 +401,8 @@ void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode
     p.max_depth = static_cast<uint32_t>(max_depth_);
     p.channel = display_channel_;
     p.sum_mode = sum_mode ? 1 : 0;
-    for (uint32_t s = 0; s < count; s++) {
-        p.spp = spp_begin + s;
-        LaunchSample(p);
-    }
+    p.spp = spp_begin;
+    LaunchSamples(p, count);
 }
 
 void PathTracer::Synchronize() {
@@ -382,7 +428,7 @@ float PathTracer::UpdateTimed(uint32_t count) {
     if (!stream_) return 0.0f;
     if (!ev_begin_) { CPT_HIP(hipEventCreate(&ev_begin_)); CPT_HIP(hipEventCreate(&ev_end_)); }
     CPT_HIP(hipEventRecord(ev_begin_, stream_));
-    for (uint32_t i = 0; i < count; i++) Update();
+    UpdateMany(count);
     CPT_HIP(hipEventRecord(ev_end_, stream_));
     CPT_HIP(hipEventSynchronize(ev_end_));
     float ms = 0.0f;

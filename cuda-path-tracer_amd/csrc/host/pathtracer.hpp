@@ -24,6 +24,10 @@ public:
     void BuildBuffers();
     void ResetAccumelation();        // [sic] the reference's spelling
     void Update();
+    // `count` more samples per pixel: the film ends up bit for bit as after `count` Update() calls, but a kernel that
+    // can render several samples per launch is launched once per SetSamplesPerLaunch() samples
+    void UpdateMany(uint32_t count);
+    void SetSamplesPerLaunch(uint32_t samples) { samples_per_launch_ = samples < 1 ? 1 : samples; }
     void ShowUi() {}                 // the interactive panel is out of scope
     void SetCaptureName(std::string_view capture_name) { capture_name_ = capture_name; }
     void SetMaxDepth(int max_depth) { max_depth_ = max_depth; }
@@ -88,7 +92,10 @@ private:
     uint32_t queue_parity_ = 0;
     int resident_blocks_ = 0;
     cpt::HipBuffer queue_;
+    cpt::HipBuffer order_;                 // one word per pixel for launches of several samples (RenderParams::order)
+    uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample
     void LaunchSample(const cpt::RenderParams &p);
+    void LaunchSamples(cpt::RenderParams p, uint32_t count);     // samples p.spp .. p.spp + count - 1
     void LaunchWavefront(const cpt::RenderParams &p);
     cpt::HipBuffer wf_state_, wf_queues_;
     cpt::WavefrontBuffers wf_{};

@@ -77,6 +77,39 @@ __device__ inline void film_accumulate(const RenderParams &p, uint32_t pixel_ind
     *out = res;
 }
 
+// The same for a launch that renders several samples per pixel: the path of the launch's k-th sample may write
+// only when the pixel has received k of them, so the pixel's samples are accumulated in sample order whatever
+// order their paths end in, and the film holds bit for bit what one launch per sample leaves.  Returns false when
+// it is not this path's turn yet (the caller tries again later; it must not spin, the earlier path may be a lane
+// of the same wave).  The film words and the turn word are device-scope atomics: a pixel's paths may run on
+// different XCDs, whose L2s do not see each other's plain stores.  They are relaxed ones, ordered by hand: an
+// acquire or release at this scope invalidates or writes back whole caches, and the traversal lives on its L1.
+// The film loads are issued after the turn word has arrived (the branch needs it), and the turn store after the
+// film stores have been acknowledged (the wait below).
+__device__ inline bool film_accumulate_in_order(const RenderParams &p, uint32_t pixel_index, uint32_t pass, V3 color) {
+    uint32_t *turn = p.order + pixel_index;
+    if (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pass) return false;
+    asm volatile("" ::: "memory");
+    if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
+    float *out = p.output + 4 * (size_t)pixel_index;
+    const float px = __hip_atomic_load(out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), py = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                pz = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pw = __hip_atomic_load(out + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float4 res;
+    if (p.sum_mode) {
+        res = make_float4(px + color.x, py + color.y, pz + color.z, pw + 1.0f);
+    } else {
+        float a = 1.0f / (float)(p.spp + pass);
+        res = make_float4(px * (1.0f - a) + color.x * a, py * (1.0f - a) + color.y * a, pz * (1.0f - a) + color.z * a, pw * (1.0f - a) + 1.0f * a);
+    }
+    __hip_atomic_store(out + 0, res.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 1, res.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 2, res.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 3, res.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(turn, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // sum over the 64 lanes of a wave, result in every lane
 __device__ inline unsigned long long wave_sum(uint32_t v) {
     unsigned long long s = v;

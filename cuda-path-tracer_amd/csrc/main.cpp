@@ -102,11 +102,15 @@ int main(int argc, char **argv) {
         path_tracer->BuildBuffers();
 
         uint32_t max_spp = std::min(static_cast<uint32_t>(cmd_args.max_spp), 65536u);
-        for (uint32_t i = 0; i < max_spp; i++) {
-            scene.Update();
-            if ((i + 1) % 16 == 0) {
+        // the reference calls scene.Update() once per sample and reports every 16th; the samples between two
+        // reports are asked for together here, which leaves the same film (PathTracer::UpdateMany)
+        for (uint32_t done = 0; done < max_spp;) {
+            const uint32_t batch = std::min(16u - done % 16u, max_spp - done);
+            path_tracer->UpdateMany(batch);
+            done += batch;
+            if (done % 16 == 0) {
                 path_tracer->Synchronize();
-                std::cout << "spp " << i + 1 << std::endl;
+                std::cout << "spp " << done << std::endl;
             }
         }
         path_tracer->Synchronize();

@@ -10,7 +10,9 @@ namespace cpt {
 // same values in locals of Trace).
 struct PathLane {
     bool alive = false, primary = false, last_specular = false;
+    bool film_pending = false;          // the path is finished and waits for its pixel's earlier samples (several samples per launch)
     uint32_t pixel_index = 0, depth = 0;
+    uint32_t pass = 0;                  // which of the launch's samples the path is: sample index - RenderParams::spp
     float last_pdf = 0.0f;
     Sampler sampler{0};
     V3 ro = v3(0.0f), rd = v3(0.0f), throughput = v3(0.0f), color = v3(0.0f);

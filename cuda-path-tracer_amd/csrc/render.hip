@@ -209,16 +209,17 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
         while (idle != 0ull && !fetch.exhausted) {
-            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane, p.spp_count)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
             const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
             const uint32_t slot = fetch.entry(rank);
             if (!s.l.alive && rank < take) {
-                const uint32_t tile = slot >> 6, k = slot & 63u;
+                const uint32_t pass = (slot >> 6) / (tiles_x * tiles_y), tile = (slot >> 6) % (tiles_x * tiles_y), k = slot & 63u;
                 const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
                 if (px < p.width && py < p.height) {
                     PathLane &l = s.l;
-                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
+                    l.pass = pass; l.film_pending = false;
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp + pass, l.sampler, l.pixel_index, l.ro, l.rd);
                     l.alive = true; l.primary = true; l.last_specular = false;
                     l.depth = 0; l.color = v3(0.0f); l.throughput = v3(1.0f);
                     s.has_ext = true;
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
             }
             if (!s.has_shadow && !t.walking()) { s.ext_traced = s.has_ext; s.has_ext = false; }
         };
-        if (s.l.alive && !t.walking()) {
+        if (s.l.alive && !t.walking() && !s.l.film_pending) {
             const Flow::Prepared ext = Flow::prepare(sc, s.l.ro, s.l.rd, kRayTMax);
             if (s.has_shadow) {
                 if (s.has_ext) {
@@ -320,16 +321,17 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
         while (idle != 0ull && !fetch.exhausted) {
-            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane, p.spp_count)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
             const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
             const uint32_t slot = fetch.entry(rank);
             if (!s.l.alive && rank < take) {
-                const uint32_t tile = slot >> 6, k = slot & 63u;
+                const uint32_t pass = (slot >> 6) / (tiles_x * tiles_y), tile = (slot >> 6) % (tiles_x * tiles_y), k = slot & 63u;
                 const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
                 if (px < p.width && py < p.height) {
                     PathLane &l = s.l;
-                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
+                    l.pass = pass; l.film_pending = false;
+                    pixel_ray(sc.camera, p.width, p.height, px, py, p.spp + pass, l.sampler, l.pixel_index, l.ro, l.rd);
                     l.alive = true; l.primary = true; l.last_specular = false;
                     l.depth = 0; l.color = v3(0.0f); l.throughput = v3(1.0f);
                     s.has_ext = true; s.has_shadow = false;
@@ -541,8 +543,10 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream) {
     uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
     if (tiles == 0) return 0;
-    uint32_t want = (tiles + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
-    uint32_t blocks = want < max_blocks ? want : max_blocks;
+    if (p.spp_count == 0 || (p.spp_count > 1 && (variant == 0 || !p.order))) return (int)hipErrorInvalidValue;
+    if ((unsigned long long)tiles * p.spp_count * kSegmentSlots > 0xffffffffull) return (int)hipErrorInvalidValue;
+    unsigned long long want = ((unsigned long long)tiles * p.spp_count + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
+    uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;
     const dim3 grid(blocks), block(kTraceBlock);
     if (variant == 2) {
         if (sc.textures) {

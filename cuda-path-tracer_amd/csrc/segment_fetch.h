@@ -46,11 +46,14 @@ struct SegmentFetchT {
     // entry number (consumed + rank), for the lanes that take one
     __device__ inline uint32_t entry(uint32_t rank) const { return __shfl(ids, (int)(consumed + rank), 64); }
 
-    __device__ inline bool fill_next(const uint32_t *queue, uint32_t *cursors, uint32_t segments, uint32_t home, uint32_t lane) {
+    // repeat (lists absent only): every range is walked `repeat` times over, pass after pass; the slots of pass k
+    // of segment s are numbered (k * segments + s) * 64 + lane
+    __device__ inline bool fill_next(const uint32_t *queue, uint32_t *cursors, uint32_t segments, uint32_t home, uint32_t lane, uint32_t repeat = 1) {
         while (visited < kCursorRanges) {
             const uint32_t r = (home + visited) % kCursorRanges;
             const uint32_t lo = (uint32_t)((unsigned long long)segments * r / kCursorRanges);
             const uint32_t size = (uint32_t)((unsigned long long)segments * (r + 1) / kCursorRanges) - lo;
+            const uint32_t turns = size * repeat;
             uint32_t *cursor = &cursors[r * kCursorStride];
             if (!claimed) {
                 // a drained range is recognised with a load, so that the waves arriving late from
@@ -58,15 +61,15 @@ struct SegmentFetchT {
                 uint32_t seen = 0;
                 if (lane == 0) {
                     seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (seen < size) claim = atomicAdd(cursor, 1u);
+                    if (seen < turns) claim = atomicAdd(cursor, 1u);
                 }
                 seen = __shfl(seen, 0, 64);
-                if (seen >= size) { visited++; continue; }
+                if (seen >= turns) { visited++; continue; }
             }
             const uint32_t s = __shfl(claim, 0, 64);
             claimed = false;
-            if (s >= size) { visited++; continue; }
-            next_ids = queue ? queue[(lo + s) * kSegmentSlots + lane] : (lo + s) * kSegmentSlots + lane;
+            if (s >= turns) { visited++; continue; }
+            next_ids = queue ? queue[(lo + s) * kSegmentSlots + lane] : ((s / size) * segments + lo + s % size) * kSegmentSlots + lane;
             next_valid = true;
             if (AHEAD) {
                 if (lane == 0) claim = atomicAdd(cursor, 1u);      // consumed by the next call
@@ -78,12 +81,12 @@ struct SegmentFetchT {
     }
 
     // takes the next non-empty segment; false (and exhausted) when every range is drained
-    __device__ inline bool advance(const uint32_t *queue, uint32_t *cursors, uint32_t segments, uint32_t home, uint32_t lane) {
+    __device__ inline bool advance(const uint32_t *queue, uint32_t *cursors, uint32_t segments, uint32_t home, uint32_t lane, uint32_t repeat = 1) {
         for (;;) {
-            if (!next_valid && !fill_next(queue, cursors, segments, home, lane)) { exhausted = true; return false; }
+            if (!next_valid && !fill_next(queue, cursors, segments, home, lane, repeat)) { exhausted = true; return false; }
             ids = next_ids;
             next_valid = false;
-            if (AHEAD) fill_next(queue, cursors, segments, home, lane);
+            if (AHEAD) fill_next(queue, cursors, segments, home, lane, repeat);
             count = (uint32_t)__popcll(__ballot(ids != kNoEntry));
             consumed = 0;
             if (count != 0) return true;

@@ -1,5 +1,5 @@
 """Small driver for rocprofv3 passes: N launches of the bounce-loop kernel on cornell-box-glass
-(no torch, no oracle).  usage: python scripts/prof_render.py [steps] [width] [depth] [integrator] [wavefront tail]"""
+(no torch, no oracle).  usage: python scripts/prof_render.py [steps] [width] [depth] [integrator] [wavefront tail] [samples per launch]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,8 +15,10 @@ tr = cpt.Tracer(scene, width, width, max_depth=depth)
 tr.set_integrator(mode)
 if len(sys.argv) > 5:
     tr.set_wavefront_tail(int(sys.argv[5]))
+if len(sys.argv) > 6:
+    tr.set_samples_per_launch(int(sys.argv[6]))
 tr.build_buffers()
-tr.update(2); tr.synchronize(); tr.reset_counters()
+tr.update(steps); tr.synchronize(); tr.reset_counters()       # same launch shape as the timed run
 ms = tr.update_timed(steps)
 c = tr.counters()
-print(f"integrator {mode}: {steps} launches {ms/steps:.4f} ms each, {width*width*steps/ms/1e3:.1f} Mpaths/s, {c['rays']/ms/1e3:.1f} Mrays/s", c)
+print(f"integrator {mode}: {steps} samples {ms/steps:.4f} ms each, {width*width*steps/ms/1e3:.1f} Mpaths/s, {c['rays']/ms/1e3:.1f} Mrays/s", c)

@@ -13,7 +13,7 @@ tail -c 1500 "$out/bench.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 256 --no-cpu-baseline --no-lbvh > "$out/stats.log" 2>&1
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
 head -4 "$out/kernel_stats.csv" | cut -c1-200
-bash scripts/pmc_passes.sh "$out/pmc" python3 scripts/prof_render.py 16 1024 8 3
+bash scripts/pmc_passes.sh "$out/pmc" python3 scripts/prof_render.py 32 1024 8 3
 python3 scripts/pmc_summary.py "$out/pmc" k_render_pool > "$out/pmc_k_render_pool.txt"
 python3 - "$out" <<'PY'
 import json, re, sys

@@ -278,6 +278,31 @@ def test_all_three_integrators_give_the_same_image_bit_for_bit(cpt, depth):
         assert rays[0] == rays[k], k
 
 
+@pytest.mark.parametrize("mode", [4, 5])
+def test_several_samples_per_launch_leave_the_same_film(cpt, mode):
+    """cpt_tracer_update_many folds up to 16 samples into one launch of the persistent kernels; a pixel's samples
+    are still accumulated in sample order, so running mean and sums are bit for bit those of one launch per sample."""
+    objs, cam = cornell(glass=True)
+    films, sums = [], []
+    for per_launch in (1, 16, 5):
+        sc, tr = gpu_scene(cpt, objs, cam, 200, 120, max_depth=8)
+        tr.set_integrator(mode)
+        tr.set_samples_per_launch(per_launch)
+        tr.update(21)
+        tr.update(1)
+        tr.update(3)
+        films.append(tr.film())
+        assert cpt.lib.cpt_tracer_current_spp(tr.h) == 25 and tr.counters()["paths"] == 200 * 120 * 25
+        buf = cpt.DeviceArray((120, 200, 4), np.float32); buf.zero()
+        tr.render_samples(7, 19, True, buf.ptr, 200, 120)
+        tr.synchronize()
+        sums.append(buf.to_host())
+    for k in (1, 2):
+        assert np.array_equal(films[0].view(np.uint32), films[k].view(np.uint32)), k
+        assert np.array_equal(sums[0].view(np.uint32), sums[k].view(np.uint32)), k
+    assert np.array_equal(sums[0][..., 3], np.full((120, 200), 19.0, np.float32))
+
+
 def test_wavefront_sum_mode_and_normal_channel(cpt):
     objs, cam = cornell(glass=False)
     out = []
