@@ -105,27 +105,25 @@ struct RayFrame {
 
 // accel.cuh:33-52 without the tmax clause; returns the entry distance in t0
 __device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayFrame &f, float tmin, float &t0) {
-    float x0, x1, y0, y1, z0, z1;
+    float t1;
     if (f.fast) {
-        x0 = div_by_recip(bminx - f.o.x, f.d.x, f.r.x);
-        x1 = div_by_recip(bmaxx - f.o.x, f.d.x, f.r.x);
-        y0 = div_by_recip(bminy - f.o.y, f.d.y, f.r.y);
-        y1 = div_by_recip(bmaxy - f.o.y, f.d.y, f.r.y);
-        z0 = div_by_recip(bminz - f.o.z, f.d.z, f.r.z);
-        z1 = div_by_recip(bmaxz - f.o.z, f.d.z, f.r.z);
+        // no quotient is a NaN here (finite numerators, directions without zeros), so ordering a pair is a min and a
+        // max: the values the compare-and-swap below produces, up to the sign of a zero, which no comparison sees
+        const float x0 = div_by_recip(bminx - f.o.x, f.d.x, f.r.x), x1 = div_by_recip(bmaxx - f.o.x, f.d.x, f.r.x);
+        const float y0 = div_by_recip(bminy - f.o.y, f.d.y, f.r.y), y1 = div_by_recip(bmaxy - f.o.y, f.d.y, f.r.y);
+        const float z0 = div_by_recip(bminz - f.o.z, f.d.z, f.r.z), z1 = div_by_recip(bmaxz - f.o.z, f.d.z, f.r.z);
+        t0 = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
+        t1 = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1)));
     } else {
-        x0 = (bminx - f.o.x) / f.d.x;
-        x1 = (bmaxx - f.o.x) / f.d.x;
-        y0 = (bminy - f.o.y) / f.d.y;
-        y1 = (bmaxy - f.o.y) / f.d.y;
-        z0 = (bminz - f.o.z) / f.d.z;
-        z1 = (bmaxz - f.o.z) / f.d.z;
+        const float x0 = (bminx - f.o.x) / f.d.x, x1 = (bmaxx - f.o.x) / f.d.x;
+        const float y0 = (bminy - f.o.y) / f.d.y, y1 = (bmaxy - f.o.y) / f.d.y;
+        const float z0 = (bminz - f.o.z) / f.d.z, z1 = (bmaxz - f.o.z) / f.d.z;
+        const float xa = x0 > x1 ? x1 : x0, xb = x0 > x1 ? x0 : x1;
+        const float ya = y0 > y1 ? y1 : y0, yb = y0 > y1 ? y0 : y1;
+        const float za = z0 > z1 ? z1 : z0, zb = z0 > z1 ? z0 : z1;
+        t0 = fmaxf(xa, fmaxf(ya, za));
+        t1 = fminf(xb, fminf(yb, zb));
     }
-    float xa = x0 > x1 ? x1 : x0, xb = x0 > x1 ? x0 : x1;
-    float ya = y0 > y1 ? y1 : y0, yb = y0 > y1 ? y0 : y1;
-    float za = z0 > z1 ? z1 : z0, zb = z0 > z1 ? z0 : z1;
-    t0 = fmaxf(xa, fmaxf(ya, za));
-    float t1 = fminf(xb, fminf(yb, zb));
     return t0 <= t1 && t1 > tmin;
 }
 
