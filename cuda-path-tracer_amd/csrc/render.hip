@@ -415,6 +415,9 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
 // the LDS stack is shortened to match (deeper entries go to private memory).
 constexpr int kQueryWaves = 8;
 constexpr int kQueryLdsEntries = 8;
+// batches are often coherent camera rays, which lose with the bounce loops' weight of 4 (heightfield 10M: 2.59 Grays/s
+// with 1 or 2, 2.46 with 4) while diverging ones gain (soup 1M: 0.67 with 1, 0.75 with 2, 0.81 with 4)
+constexpr int kQueryLeafWeightLargeScene = 2;
 
 template <bool LARGE>
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev s
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
