@@ -303,6 +303,26 @@ def test_several_samples_per_launch_leave_the_same_film(cpt, mode):
     assert np.array_equal(sums[0][..., 3], np.full((120, 200), 19.0, np.float32))
 
 
+@pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9)])
+def test_tiny_films_and_ragged_batches(cpt, size):
+    """Films smaller than one 8x8 tile or one wave, a sample count that is not a multiple of the launch size,
+    depth 0 (camera rays only): every integrator leaves the same film."""
+    W, H = size
+    objs, cam = cornell(glass=True)
+    for depth in (0, 3):
+        films = []
+        for mode in (0, 1, 2, 4, 5):
+            sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=depth)
+            tr.set_integrator(mode)
+            tr.update(33)
+            tr.update(2)
+            films.append(tr.film())
+            assert films[-1].shape == (H, W, 4) and tr.counters()["paths"] == W * H * 35
+        for k in range(1, len(films)):
+            assert np.array_equal(films[0].view(np.uint32), films[k].view(np.uint32)), (depth, k)
+        assert np.all(films[0][..., 3] == 1.0)
+
+
 def test_wavefront_sum_mode_and_normal_channel(cpt):
     objs, cam = cornell(glass=False)
     out = []
