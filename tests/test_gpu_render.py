@@ -303,6 +303,28 @@ def test_several_samples_per_launch_leave_the_same_film(cpt, mode):
     assert np.array_equal(sums[0][..., 3], np.full((120, 200), 19.0, np.float32))
 
 
+@pytest.mark.parametrize("mode,kind", [(5, "cornell"), (4, "soup")])
+def test_full_size_film_does_not_depend_on_samples_per_launch(cpt, mode, kind):
+    """At the metric's size every CU is busy and waves take tiles from other XCDs' bands when theirs are drained, so a
+    pixel's samples do run on different XCDs: 64 samples in launches of 32 against one launch per sample."""
+    if kind == "cornell":
+        objs, cam = cornell(glass=True)
+        W = H = 1024
+        depth = 8
+    else:
+        objs, cam = synthetic_scene("soup", 70000)
+        W, H, depth = 1920, 1080, 5
+    films = []
+    for per_launch in (1, 32):
+        sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=depth)
+        tr.set_integrator(mode)
+        tr.set_samples_per_launch(per_launch)
+        tr.update(64)
+        films.append(tr.film())
+        assert tr.counters()["paths"] == W * H * 64
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+
+
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9)])
 def test_tiny_films_and_ragged_batches(cpt, size):
     """Films smaller than one 8x8 tile or one wave, a sample count that is not a multiple of the launch size,
