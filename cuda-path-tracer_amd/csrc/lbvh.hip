@@ -503,8 +503,13 @@ __device__ inline void climb_global(uint32_t l, uint32_t r, uint32_t idx, uint32
     };
     uint32_t lc = 0, rc = 0;
     bool have_record = true;
+    // While n < 2^24 an exchange word has room for the prefix length beyond the range's far end next to the far
+    // end itself, so the node that merges two ranges knows both of its outer prefix lengths without reading keys
+    // again: one memory round trip less per level of a climb whose levels are nothing but round trips.
+    const bool packed = n < (1u << 24);
+    int dl = delta_before(l), dr = delta_before(r + 1);
     for (;;) {
-        const bool left_child = delta_before(r + 1) > delta_before(l);
+        const bool left_child = dr > dl;
         const uint32_t g = left_child ? r : l - 1;
         if (!have_record) {
             idx = left_child ? r : l;
@@ -522,17 +527,20 @@ __device__ inline void climb_global(uint32_t l, uint32_t r, uint32_t idx, uint32
             }
             store_box_sc1(bboxes + idx, olo, ohi);
         }
-        const uint32_t far = (left_child ? l : r) | kSlotValid;
+        uint32_t far = (left_child ? l : r) | kSlotValid;
+        if (packed) far |= (uint32_t)((left_child ? dl : dr) + 1) << 24;
         const uint32_t prev = __hip_atomic_exchange(&slots[g], far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == 0) return;
-        const uint32_t sib_far = prev & ~kSlotValid;
+        const uint32_t sib_far = packed ? (prev & 0x00ffffffu) : (prev & ~kSlotValid);
         uint32_t sib;
         if (left_child) {                                  // sibling = right child, keys [g+1, sib_far]
             sib = sib_far == g + 1 ? (n - 1) + g + 1 : g + 1;
             lc = idx; rc = sib; r = sib_far;
+            dr = packed ? (int)((prev >> 24) & 0x7fu) - 1 : delta_before(r + 1);
         } else {                                           // sibling = left child, keys [sib_far, g]
             sib = sib_far == g ? (n - 1) + g : g;
             lc = sib; rc = idx; l = sib_far;
+            dl = packed ? (int)((prev >> 24) & 0x7fu) - 1 : delta_before(l);
         }
         f32x4 a4, b4;
         load_box_sc1(bboxes + sib, a4, b4);

@@ -112,7 +112,7 @@ def check_tree_properties(nodes, boxes, keys, leaf_boxes, merged):
     assert np.array_equal(boxes[0, 0:3], leaf_boxes[:, 0:3].min(axis=0)) and np.array_equal(boxes[0, 4:7], leaf_boxes[:, 4:7].max(axis=0))
 
 
-@pytest.mark.parametrize("n,kind", [(1_000_000, "soup"), (1_000_000, "heightfield"), (10_000_000, "soup")])
+@pytest.mark.parametrize("n,kind", [(1_000_000, "soup"), (1_000_000, "heightfield"), (10_000_000, "soup"), (17_000_000, "soup")])     # the last one: exchange words without the packed prefix length (n >= 2^24)
 def test_full_size_builds(cpt, n, kind):
     if kind == "soup":
         mesh = random_soup(n, seed=12345)
