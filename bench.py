@@ -4,14 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): cornell-box-glass, 1024x1024, max depth 8, glass (dielectric)
-box, 1 sample per pixel per step; the default K = 1024 steps is the full 1024-spp render.  One step
-is one launch of the bounce-loop megakernel over every pixel.  With N > 1 every rank renders its own
+Workload (the configuration the headline metric is quoted on): cornell-box-glass, 1024x1024, max
+depth 8, glass (dielectric) box, 1 sample per pixel per step; the default K = 1024 steps is the full
+1024-spp render.  One step is one sample of every pixel; the persistent kernels render
+--samples-per-launch of them per launch, leaving the film of one launch per sample bit for bit.
+With N > 1 every rank renders its own
 block of K sample indices into a sum buffer (weak scaling, no data-path collective) and the timed
 region ends with one sum-reduce of the 16.8 MB buffers to rank 0 (RCCL through torch.distributed).
 
---workload heightfield-10m (etc.) renders a synthetic scene of the named size instead (BASELINE.json
-configs 3-5), --integrator picks the bounce-loop variant; the defaults are the metric's configuration.
+--workload heightfield-10m (etc.) renders a synthetic scene of the named size instead (the 1M / 10M
+triangle configurations), --integrator picks the bounce-loop variant; the defaults are the metric's configuration.
 
 Prints ONE JSON line on rank 0.  Scene data comes from tests/golden/scenes (data fixtures);
 nothing outside this repository is read.  The oracle (oracle/) is used only for the `cpu_baseline`

@@ -1,4 +1,4 @@
-"""Synthetic-scene numbers (BASELINE configs 3-5): LBVH build through the tracer, primary-ray
+"""Synthetic-scene numbers (the 1M / 10M triangle configurations): LBVH build through the tracer, primary-ray
 first-hit rate and path-tracing rate.  usage: python scripts/bench_synth.py <kind> <ntris> [width height spp depth integrators]
 integrators: comma list of mode[:wavefront tail], e.g. 0,1,2:-1,2:3"""
 import os, sys, time
