@@ -154,6 +154,13 @@ CPT_HD float lambert_pdf(V3 wo, V3 wi) { return wo.z * wi.z >= 0.0f ? fabsf(wi.z
 CPT_HD V3 lambert_eval(const BsdfDev &b, V3 wo, V3 wi) { return wo.z * wi.z >= 0.0f ? b.diffuse * fabsf(wi.z) * kInvPi : v3(0.0f); }
 
 // ---- Blinn-Phong (bsdf/blinn_phong.cuh:15-75)
+// pow(h.z, shininess) where the reference computes it.  With a specular colour of zero every use multiplies it by
+// a zero, and a finite factor then leaves no trace in the result, bit for bit; it is finite for h.z >= 0.  (For
+// h.z < 0 it is a NaN that does reach the result, so it is evaluated.)  The Cornell scenes have Ks = 0 throughout.
+CPT_HD float blinn_lobe(const BsdfDev &b, float hz, float specular_pdf) {
+    const bool unused = b.specular.x == 0.0f && b.specular.y == 0.0f && b.specular.z == 0.0f && specular_pdf == 0.0f && hz >= 0.0f;
+    return unused ? 0.0f : powf(hz, b.shininess);
+}
 CPT_HD BsdfSample blinn_sample(const BsdfDev &b, V3 wo, float r1, V2 r2) {
     float diffuse_weight = luminance(b.diffuse), specular_weight = luminance(b.specular);
     float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
@@ -167,7 +174,7 @@ CPT_HD BsdfSample blinn_sample(const BsdfDev &b, V3 wo, float r1, V2 r2) {
         samp.lobe = kLobeDiffuse;
         d = fabsf(samp.wi.z) * kInvPi;
         h = reflect_half(samp.wi, wo);
-        s = powf(h.z, b.shininess);
+        s = blinn_lobe(b, h.z, specular_pdf);
     } else {
         float phi = r2.x * k2Pi;
         float sin_phi = sinf(phi), cos_phi = cosf(phi);
@@ -190,14 +197,14 @@ CPT_HD float blinn_pdf(const BsdfDev &b, V3 wo, V3 wi) {
     float diffuse_pdf = diffuse_weight / (diffuse_weight + specular_weight);
     float specular_pdf = 1.0f - diffuse_pdf;
     V3 h = reflect_half(wi, wo);
-    float half_pdf = powf(h.z, b.shininess) * (2.0f + b.shininess) * kInv2Pi;
+    float half_pdf = blinn_lobe(b, h.z, specular_pdf) * (2.0f + b.shininess) * kInv2Pi;
     return diffuse_pdf * fabsf(wi.z) * kInvPi + specular_pdf * half_pdf / (4.0f * fabsf(dot(wi, h)));
 }
 CPT_HD V3 blinn_eval(const BsdfDev &b, V3 wo, V3 wi) {
     if (wo.z * wi.z <= 0.0f) return v3(0.0f);
     V3 h = reflect_half(wi, wo);
     V3 d = b.diffuse * fabsf(wi.z) * kInvPi;
-    V3 s = b.specular * powf(h.z, b.shininess) * b.s_norm;
+    V3 s = b.specular * blinn_lobe(b, h.z, 0.0f) * b.s_norm;
     return d + s;
 }
 
