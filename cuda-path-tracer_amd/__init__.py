@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpt_amd.so")
+LIB_PATH = os.environ.get("CPT_AMD_LIBRARY") or os.path.join(_HERE, "libcpt_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cpt_amd.h")
 
 if not os.path.exists(LIB_PATH):

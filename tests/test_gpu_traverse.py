@@ -73,6 +73,18 @@ def test_cornell_camera_and_interior_rays(cpt, glass):
     assert_same_hits(tr, osc, rays)
     sh = interior_rays(100000, 6, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32), tmax=0.9)
     assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
+    # origins with -0 and +0 coordinates: every instance of this scene has the identity transform, whose product
+    # with the origin turns a -0 into +0 or keeps it depending on the other terms (accel.cuh:54-59)
+    rays = interior_rays(60000, 7, np.array([-1, 0, -1], np.float32), np.array([1, 2, 1], np.float32))
+    for k in range(3):
+        rays[k * 10000:(k + 1) * 10000, k] = -0.0
+        rays[30000 + k * 10000:30000 + (k + 1) * 10000, k] = 0.0
+    rays[5000:10000, 1] = -0.0
+    rays[15000:20000, 2] = -0.0
+    assert_same_hits(tr, osc, rays)
+    sh = rays.copy()
+    sh[:, 7] = 0.9
+    assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
 
 
 def test_transformed_instances(cpt):
