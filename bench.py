@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--integrator", type=int, default=3,
                     help="3 by scene size (default: 5 for the Cornell box, 4 for the synthetic scenes), 0 persistent megakernel, 1 megakernel, "
                          "2 wavefront, 4 persistent megakernel that shades partly finished waves, 5 persistent megakernel with pooled shadow rays")
-    ap.add_argument("--samples-per-launch", type=int, default=32,
+    ap.add_argument("--samples-per-launch", type=int, default=128,
                     help="samples (steps) the persistent kernels of integrators 4 and 5 render per launch; the film is bit for bit "
                          "that of one launch per sample (1 = one launch per sample, as the reference launches RenderKernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -259,7 +259,9 @@ def main():
             if os.path.exists(tpath) and args.workload == "cornell-box-glass" and (W, H, args.max_depth) == (1024, 1024, 8):
                 try:
                     measured = json.load(open(tpath))
-                    traffic = measured.get("hbm_bytes_per_launch") if measured.get("kernel") == kernel_name else None
+                    # counters taken on launches of the same number of samples only
+                    same = measured.get("kernel") == kernel_name and measured.get("samples_per_launch", 32) == per_launch
+                    traffic = measured.get("hbm_bytes_per_launch") if same else None
                 except Exception:
                     traffic = None
             result["roofline"] = {"kernel": kernel_name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -440,7 +440,7 @@ int cpt_tracer_update_many(cpt_tracer *t, uint32_t count) {
 }
 int cpt_tracer_set_samples_per_launch(cpt_tracer *t, uint32_t samples) {
     TRACER_OR_FAIL(t);
-    if (samples < 1 || samples > 64) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_samples_per_launch: 1 to 64");
+    if (samples < 1 || samples > 4096) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_samples_per_launch: 1 to 4096");
     t->tracer->SetSamplesPerLaunch(samples);
     return CPT_OK;
 }

@@ -93,7 +93,7 @@ private:
     int resident_blocks_ = 0;
     cpt::HipBuffer queue_;
     cpt::HipBuffer order_;                 // one word per pixel for launches of several samples (RenderParams::order)
-    uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample
+    uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample (later, with 0.824 at 32: 64 -> 0.817, 128 -> 0.814, 256 -> 0.813, 1024 -> 0.811)
     void LaunchSample(const cpt::RenderParams &p);
     void LaunchSamples(cpt::RenderParams p, uint32_t count);     // samples p.spp .. p.spp + count - 1
     void LaunchWavefront(const cpt::RenderParams &p);

@@ -141,7 +141,7 @@ int cpt_tracer_set_profile_build(cpt_tracer *t, int on);
 int cpt_tracer_build_buffers(cpt_tracer *t);                        /* PathTracer::BuildBuffers */
 int cpt_tracer_update(cpt_tracer *t);                               /* PathTracer::Update: one more sample per pixel (asynchronous) */
 /* `count` more samples per pixel: the film ends up bit for bit as after `count` calls of cpt_tracer_update, but the
- * persistent kernels of integrator modes 4 and 5 render up to cpt_tracer_set_samples_per_launch (default 32, 1 =
+ * persistent kernels of integrator modes 4 and 5 render up to cpt_tracer_set_samples_per_launch (1 to 4096, default 32, 1 =
  * one launch per sample) consecutive samples in one launch, a pixel's samples still arriving in sample order.
  * The reference launches RenderKernel once per sample (src/pathtracer/pathtracer.cpp:26-61); at 1024 x 1024 the
  * start of a launch and the tail of its longest paths cost about a third of the launch. */
