@@ -306,7 +306,7 @@ def test_several_samples_per_launch_leave_the_same_film(cpt, mode):
 @pytest.mark.parametrize("mode,kind", [(5, "cornell"), (4, "soup")])
 def test_full_size_film_does_not_depend_on_samples_per_launch(cpt, mode, kind):
     """At the metric's size every CU is busy and waves take tiles from other XCDs' bands when theirs are drained, so a
-    pixel's samples do run on different XCDs: 64 samples in launches of 32 against one launch per sample."""
+    pixel's samples do run on different XCDs: 128 samples in launches of 32 and of 128 against one launch per sample."""
     if kind == "cornell":
         objs, cam = cornell(glass=True)
         W = H = 1024
@@ -315,14 +315,17 @@ def test_full_size_film_does_not_depend_on_samples_per_launch(cpt, mode, kind):
         objs, cam = synthetic_scene("soup", 70000)
         W, H, depth = 1920, 1080, 5
     films = []
-    for per_launch in (1, 32):
+    for per_launch in (1, 32, 128):     # 128 is what bench.py renders with
         sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=depth)
         tr.set_integrator(mode)
         tr.set_samples_per_launch(per_launch)
-        tr.update(64)
+        tr.update(128)
         films.append(tr.film())
-        assert tr.counters()["paths"] == W * H * 64
+        assert tr.counters()["paths"] == W * H * 128
     assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+    assert np.array_equal(films[0].view(np.uint32), films[2].view(np.uint32))
+    assert cpt.lib.cpt_tracer_set_samples_per_launch(tr.h, 4096) == 0 and cpt.lib.cpt_tracer_set_samples_per_launch(tr.h, 4097) != 0
+    assert cpt.lib.cpt_tracer_set_samples_per_launch(tr.h, 0) != 0
 
 
 @pytest.mark.parametrize("size", [(1, 1), (7, 3), (65, 9)])
