@@ -46,6 +46,15 @@ def test_random_soup(cpt, n):
     assert_same_build(cpt, boxes, merged)
 
 
+def test_random_soup_above_the_small_sort_limit(cpt):
+    """Inputs above 3M keys take the other launch shapes of the build (one key per lane in the key kernel, 16 keys per
+    lane in the sort, no fused digit count): the same bit-for-bit comparison with the oracle, at 3.2M triangles."""
+    soup = random_soup(3_200_000, seed=77)
+    boxes, merged = boxes_of_triangles(soup["positions"], soup["indices"])
+    del soup
+    assert_same_build(cpt, boxes, merged)
+
+
 def test_heightfield(cpt):
     hf = heightfield(300, 300)
     boxes, merged = boxes_of_triangles(hf["positions"], hf["indices"])
