@@ -46,6 +46,8 @@ _sig("cpt_memset", C.c_int, [_vp, C.c_int, C.c_size_t])
 _sig("cpt_synchronize", C.c_int, [])
 _sig("cpt_build_accel", C.c_int, [_vp, _vp, _f32, C.c_uint32])
 _sig("cpt_build_accel_ex", C.c_int, [_vp, _vp, _f32, C.c_uint32, _vp, _vp, _vp])
+_sig("cpt_build_accel_noalloc", C.c_int, [_vp, _vp, _f32, C.c_uint32])
+_sig("cpt_build_accel_noalloc_max_primitives", C.c_uint32, [])
 _sig("cpt_builder_create", _vp, [])
 _sig("cpt_builder_destroy", None, [_vp])
 _sig("cpt_builder_set_sort", C.c_int, [_vp, C.c_int])

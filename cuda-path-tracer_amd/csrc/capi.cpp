@@ -117,6 +117,17 @@ int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8]
     return e == hipSuccess ? CPT_OK : HipFail(e, "lbvh_build");
 }
 
+int cpt_build_accel_noalloc(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives) {
+    if (num_primitives == 0) return CPT_OK;
+    if (!d_nodes || !d_bboxes || !merged_bbox) return Fail(CPT_ERR_INVALID, "cpt_build_accel_noalloc: null argument");
+    if (num_primitives > cpt::lbvh_static_max_primitives())
+        return Fail(CPT_ERR_INVALID, "cpt_build_accel_noalloc: " + std::to_string(num_primitives) + " primitives, the fixed scratch array holds at most " +
+                                         std::to_string(cpt::lbvh_static_max_primitives()) + " (use cpt_build_accel)");
+    int rc = cpt::lbvh_build_static(static_cast<cpt::AccelNode *>(d_nodes), static_cast<cpt::Bbox *>(d_bboxes), MakeBox(merged_bbox), num_primitives, nullptr);
+    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "lbvh_build_static");
+}
+uint32_t cpt_build_accel_noalloc_max_primitives(void) { return cpt::lbvh_static_max_primitives(); }
+
 cpt_builder *cpt_builder_create(void) { return new cpt_builder(); }
 
 void cpt_builder_destroy(cpt_builder *b) {

@@ -16,6 +16,7 @@ struct BuildWorkspace {
     // nodes per workgroup of the first hierarchy pass that may be handed to the second pass (at most 64, the
     // default); the rest climbs inside the first pass.  Lower values exist to exercise that path in tests.
     uint32_t carrier_limit = 64;
+    bool borrowed = false;          // `base` belongs to someone else: never freed, never grown
     static size_t bytes_for(uint32_t num_primitives);
     int reserve(uint32_t num_primitives);
     void release();
@@ -34,6 +35,13 @@ struct BuildWorkspace {
 // Returns 0 or a hipError_t value.
 int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t num_primitives, hipStream_t stream, BuildWorkspace *ws,
                const Bbox *leaf_src, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms);
+
+// The same build (in place, leaf boxes pre-filled, returns when it has finished) with all scratch in a device
+// array of fixed size inside the library: no allocation of any kind.  At most kStaticMaxPrimitives primitives
+// (hipErrorInvalidValue beyond).  Calls on one GPU share that array: two of them at the same time race.
+constexpr uint32_t kStaticMaxPrimitives = 1u << 20;
+uint32_t lbvh_static_max_primitives();
+int lbvh_build_static(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t num_primitives, hipStream_t stream);
 
 // Leaf boxes of a triangle mesh (w = 1), the device counterpart of src/scene/mesh.cpp:88-98.
 int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);

@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 namespace cpt {
 
 namespace {
@@ -855,6 +857,7 @@ size_t BuildWorkspace::bytes_for(uint32_t n) {
 int BuildWorkspace::reserve(uint32_t n) {
     size_t need = bytes_for(n);
     if (need <= capacity) return 0;
+    if (borrowed) return (int)hipErrorOutOfMemory;       // memory that is not this workspace's to grow
     if (base) { HIP_OK(hipFree(base)); base = nullptr; capacity = 0; }
     HIP_OK(hipMalloc(&base, need));
     capacity = need;
@@ -862,7 +865,7 @@ int BuildWorkspace::reserve(uint32_t n) {
 }
 
 void BuildWorkspace::release() {
-    if (base) (void)hipFree(base);
+    if (base && !borrowed) (void)hipFree(base);
     base = nullptr;
     capacity = 0;
 }
@@ -975,6 +978,48 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     }
     if (!ws_in) local.release();                // the temporaries die with this call, as in the reference
     return sort_failed ? (int)hipErrorLaunchFailure : 0;
+}
+
+// ---- the build with its scratch in a fixed device array: no allocation, ever ------------------------------
+// Every GPU this library runs on holds its own copy of the array (at its own address) from the moment the code
+// object is loaded until the process ends.  The name `scratch` is only a host-side handle for that symbol: the
+// device address is asked for once per device and kept, and only that address goes to kernels and memsets.
+constexpr size_t kStaticScratchBytes = 60u << 20;        // what 2^20 primitives need (56.2 MiB), rounded up
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_static_mutex;
+static void *g_static_ptr[kMaxDevices];                  // per device: address of that device's `scratch`
+
+uint32_t lbvh_static_max_primitives() { return kStaticMaxPrimitives; }
+
+int lbvh_build_static(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n > kStaticMaxPrimitives || BuildWorkspace::bytes_for(n) > kStaticScratchBytes) return (int)hipErrorInvalidValue;
+    int device = -1;
+    HIP_OK(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return (int)hipErrorInvalidDevice;
+    void *ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        if (!g_static_ptr[device]) {
+            void *p = nullptr;
+            HIP_OK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));        // with `device` current: that device's copy
+            if (!p) return (int)hipErrorInvalidSymbol;
+            g_static_ptr[device] = p;
+        }
+        ptr = g_static_ptr[device];
+    }
+    BuildWorkspace ws;
+    ws.base = ptr;
+    ws.capacity = kStaticScratchBytes;
+    ws.borrowed = true;
+    // Everything the kernels expect to start at zero (exchange words, tile counts) is cleared or fully rewritten by
+    // the build itself, as for any reused workspace, so the previous call's contents do not matter.
+    int rc = lbvh_build(nodes, bboxes, merged, n, stream, &ws, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
 }
 
 int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t n, hipStream_t stream) {

@@ -61,6 +61,16 @@ int cpt_build_accel(void *d_nodes, void *d_bboxes, const float merged_bbox[8], u
 int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives, uint64_t *d_keys_out,
                        uint32_t *d_parents_out, float *stage_ms);
 
+/* cpt_build_accel for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference, whose BuildAccel allocates and frees two temporaries per
+ * call (src/kernels/accel/accel_build.cu:187-199).  Same arguments, same in-place result, returns after the build has
+ * completed; all scratch (keys, the copy of the leaf boxes, exchange words, digit counts) lives in one device array of
+ * 60 MiB inside the library, which every GPU the library runs on holds until the process ends.  Calls no hipMalloc /
+ * hipFree.  At most cpt_build_accel_noalloc_max_primitives() = 1,048,576 primitives: CPT_ERR_INVALID beyond.  All
+ * calls on one GPU share that array, so two calls that overlap on the same GPU race; calls on different GPUs do not. */
+int cpt_build_accel_noalloc(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives);
+uint32_t cpt_build_accel_noalloc_max_primitives(void);
+
 /* Reusable-scratch variant for timing loops: the scratch lives in the handle, no allocation
  * happens after the first call of a given size, and the call only enqueues work (synchronise with
  * cpt_synchronize).  elapsed_ms (optional) receives the device time of this build and forces a sync. */
