@@ -94,6 +94,7 @@ _sig("cpt_tracer_occlude", C.c_int, [_vp, _vp, C.c_uint64, _vp])
 _sig("cpt_tracer_camera_rays", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp])
 _sig("cpt_tracer_get_accel", C.c_int64, [_vp, C.c_int, _vp, _vp, _vp])
 _sig("cpt_tracer_counters", C.c_int, [_vp, _vp])
+_sig("cpt_tracer_stack_overflows", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_counters", C.c_int, [_vp])
 _sig("cpt_tracer_build_stage_ms", C.c_int, [_vp, _vp])
 _sig("cpt_selftest_division", C.c_int, [C.c_uint64, C.c_uint32, _vp])
@@ -399,6 +400,12 @@ class Tracer:
         out = np.zeros(5, dtype=np.uint64)
         check(lib.cpt_tracer_counters(self.h, out.ctypes.data))
         return dict(rays=int(out[0]), node_visits=int(out[1]), tri_tests=int(out[2]), paths=int(out[3]), shades=int(out[4]))
+
+    def stack_overflows(self):
+        """Traversal stack entries dropped since the last counter reset (0 = every traversal was complete)."""
+        out = C.c_uint64(0)
+        check(lib.cpt_tracer_stack_overflows(self.h, C.byref(out)))
+        return int(out.value)
 
     def reset_counters(self):
         check(lib.cpt_tracer_reset_counters(self.h))

@@ -474,9 +474,19 @@ int cpt_tracer_timer_end(cpt_tracer *t, float *elapsed_ms) {
 int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]) {
     TRACER_OR_FAIL(t);
     return Guard([&] {
-        unsigned long long c[5];
+        unsigned long long c[6];
         t->tracer->ReadCounters(c);
         for (int i = 0; i < 5; i++) out5[i] = c[i];
+        return CPT_OK;
+    });
+}
+int cpt_tracer_stack_overflows(cpt_tracer *t, uint64_t *count) {
+    TRACER_OR_FAIL(t);
+    if (!count) return Fail(CPT_ERR_INVALID, "cpt_tracer_stack_overflows: null argument");
+    return Guard([&] {
+        unsigned long long c[6];
+        t->tracer->ReadCounters(c);
+        *count = c[5];
         return CPT_OK;
     });
 }

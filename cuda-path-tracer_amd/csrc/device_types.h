@@ -103,6 +103,7 @@ struct alignas(64) Counters {
     unsigned long long tri_tests;   // triangle records fetched
     unsigned long long paths;       // camera paths started
     unsigned long long shades;      // shading surfaces evaluated (vertex fetch + material read)
+    unsigned long long stack_overflows; // traversal stack entries dropped for lack of room (slot 0 only); 0 = every traversal was complete
 };
 constexpr uint32_t kCounterSlots = 1024;
 

@@ -436,14 +436,14 @@ float PathTracer::UpdateTimed(uint32_t count) {
     return ms;
 }
 
-void PathTracer::ReadCounters(unsigned long long out[5]) {
-    for (int i = 0; i < 5; i++) out[i] = 0;
+void PathTracer::ReadCounters(unsigned long long out[6]) {
+    for (int i = 0; i < 6; i++) out[i] = 0;
     if (!counters_.Size()) return;
     std::vector<cpt::Counters> slots(cpt::kCounterSlots);
     CPT_HIP(hipMemcpyAsync(slots.data(), counters_.GpuData(), sizeof(cpt::Counters) * cpt::kCounterSlots, hipMemcpyDeviceToHost, stream_));
     CPT_HIP(hipStreamSynchronize(stream_));
     for (const cpt::Counters &c : slots) {
-        out[0] += c.rays; out[1] += c.node_visits; out[2] += c.tri_tests; out[3] += c.paths; out[4] += c.shades;
+        out[0] += c.rays; out[1] += c.node_visits; out[2] += c.tri_tests; out[3] += c.paths; out[4] += c.shades; out[5] += c.stack_overflows;
     }
 }
 

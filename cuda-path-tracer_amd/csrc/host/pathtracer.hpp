@@ -48,7 +48,8 @@ public:
     // Renders sample indices [spp_begin, spp_begin + count) (1-based) into `output` (device,
     // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
     void RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height);
-    void ReadCounters(unsigned long long out[5]);
+    // rays, node records, triangle records, paths, shading surfaces, traversal stack entries dropped (0 = all traversals complete)
+    void ReadCounters(unsigned long long out[6]);
     // `count` Update() calls bracketed by events on the tracer's stream; returns device milliseconds
     float UpdateTimed(uint32_t count);
     // device time between two points of the tracer's stream: TimerBegin records, TimerEnd records, waits and returns ms

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStack st(s_stack, spill_entries);
+    TraceStack st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t tiles_x = (p.width + 15) / 16;
     const uint32_t tile = xcd_band_remap(blockIdx.x, gridDim.x);
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
     __shared__ uint2 s_stack[RegenShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<RegenShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<RegenShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
     __shared__ unsigned long long s_cnt[5];
     __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene> st(s_stack, spill_entries);      // the build for large scenes
+    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     __shared__ float4 s_pool[4 * kTraceBlock];
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev s
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {

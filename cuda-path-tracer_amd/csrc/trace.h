@@ -48,12 +48,18 @@ struct TraceStackT {
     static constexpr int kLeafWeight = LEAF_WEIGHT;
     LdsStack lds;
     PrivateStack spill;
-    __device__ inline TraceStackT(uint2 *shared_entries, uint2 *private_entries)
-        : lds((LdsStack)shared_entries), spill((PrivateStack)private_entries) {}
+    Counters *counters;       // where an entry that does not fit is reported (may be null)
+    __device__ inline TraceStackT(uint2 *shared_entries, uint2 *private_entries, Counters *report)
+        : lds((LdsStack)shared_entries), spill((PrivateStack)private_entries), counters(report) {}
+    // An entry beyond LDS_ENTRIES + kSpillEntries pending subtrees is dropped: that subtree is never walked (at()
+    // returns an entry that is never entered) and the drop is counted, so a caller can tell a complete traversal
+    // (count 0) from one that may have missed a hit.  The reference keeps 32 entries and writes past its array
+    // beyond them (accel.cuh:69).
     __device__ inline void push(uint32_t sp, uint32_t node, float t0) {
         RawU2 e = {node, __float_as_uint(t0)};
         if (sp < LDS_ENTRIES) lds[sp * kTraceBlock + threadIdx.x] = e;
         else if (sp < LDS_ENTRIES + kSpillEntries) spill[sp - LDS_ENTRIES] = e;
+        else if (counters) atomicAdd(&counters->stack_overflows, 1ull);
     }
     __device__ inline uint2 at(uint32_t sp) const {
         RawU2 e = {0u, 0x7fc00000u};          // NaN entry distance: never entered

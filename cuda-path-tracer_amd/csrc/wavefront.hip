@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k
     __shared__ uint2 s_stack[QueueTraceShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries);
+    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, Rende
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStack st(s_stack, spill_entries);
+    TraceStack st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;

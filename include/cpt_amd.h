@@ -196,6 +196,10 @@ int64_t cpt_tracer_get_accel(cpt_tracer *t, int mesh, uint32_t *nodes, float *bb
 /* counters since the last reset: rays (closest + any hit queries), 64-byte node records
  * fetched, triangle records fetched, camera paths started, shading surfaces evaluated */
 int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]);
+/* Traversal stack entries dropped since the last reset.  A lane keeps up to 56-64 pending subtrees (8-16 in LDS,
+ * 48 in private memory; the reference keeps 32 and has undefined behaviour beyond, src/kernels/accel/accel.cuh:69);
+ * a subtree that does not fit is skipped and counted here.  0 means every traversal so far was complete. */
+int cpt_tracer_stack_overflows(cpt_tracer *t, uint64_t *count);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
 

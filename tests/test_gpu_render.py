@@ -1,7 +1,7 @@
 """GPU: the bounce loop against the oracle.  Random streams are identical on both sides and the
 ray/scene arithmetic is bit-exact, so images differ only through last-ulp differences between the
 device and host sinf/cosf/powf (a handful of paths flip a decision).  Stated tolerance: relative
-L2 error <= 1e-2 and per-channel mean within 1e-3 relative at 16 spp on a 64x64 image."""
+L2 error <= 1e-3 (measured: 1e-8 to 1e-4) and per-channel mean within 1e-3 relative at 16 spp on a 64x64 image."""
 import os
 import subprocess
 import sys
@@ -15,7 +15,7 @@ from test_gpu_traverse import gpu_scene
 
 pytestmark = pytest.mark.gpu
 
-REL_L2_TOL = 1e-2
+REL_L2_TOL = 1e-3
 MEAN_TOL = 1e-3
 
 
