@@ -65,6 +65,7 @@ _sig("cpt_scene_num_objects", C.c_uint32, [_vp])
 _sig("cpt_scene_object_info", C.c_int, [_vp, C.c_uint32, C.c_char_p, C.c_size_t, _vp, _vp, _vp, _vp])
 _sig("cpt_scene_object_copy", C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp])
 _sig("cpt_scene_object_set_trs", C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp])
+_sig("cpt_scene_object_set_material", C.c_int, [_vp, C.c_uint32, _f32])
 _sig("cpt_scene_object_transforms", C.c_int, [_vp, C.c_uint32, _vp, _vp])
 _sig("cpt_scene_camera", C.c_int, [_vp, _vp, _vp])
 _sig("cpt_tracer_create", _vp, [_vp, C.c_uint32, C.c_uint32])
@@ -97,6 +98,23 @@ _sig("cpt_tracer_counters", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_stack_overflows", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_counters", C.c_int, [_vp])
 _sig("cpt_tracer_build_stage_ms", C.c_int, [_vp, _vp])
+_sig("cpt_shard_samples", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp])
+_sig("cpt_comm_unique_id", C.c_int, [_vp])
+_sig("cpt_comm_create", _vp, [_vp, C.c_int, C.c_int])
+_sig("cpt_comm_destroy", None, [_vp])
+_sig("cpt_tracer_reduce_film", C.c_int, [_vp, _vp, C.c_int, C.c_int])
+_sig("cpt_multi_create", _vp, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32])
+_sig("cpt_multi_destroy", None, [_vp])
+_sig("cpt_multi_set_max_depth", C.c_int, [_vp, C.c_int])
+_sig("cpt_multi_set_integrator", C.c_int, [_vp, C.c_int])
+_sig("cpt_multi_set_samples_per_launch", C.c_int, [_vp, C.c_uint32])
+_sig("cpt_multi_build_buffers", C.c_int, [_vp])
+_sig("cpt_multi_render", C.c_int, [_vp, C.c_uint32, _vp])
+_sig("cpt_multi_film_read", C.c_int, [_vp, _f32])
+_sig("cpt_multi_film_save", C.c_int, [_vp, C.c_char_p])
+_sig("cpt_multi_counters", C.c_int, [_vp, _vp])
+_sig("cpt_multi_reset_counters", C.c_int, [_vp])
+_sig("cpt_multi_num_devices", C.c_uint32, [_vp])
 _sig("cpt_selftest_division", C.c_int, [C.c_uint64, C.c_uint32, _vp])
 _sig("cpt_stream_copy_rate", C.c_int, [C.c_uint64, C.c_int, _vp])
 _sig("cpt_write_exr", C.c_int, [C.c_char_p, _f32, C.c_uint32, C.c_uint32])
@@ -270,6 +288,10 @@ class Scene:
         check(lib.cpt_scene_object_set_trs(self.h, index, t.ctypes.data, r.ctypes.data, s.ctypes.data))
         return self
 
+    def set_material(self, index, material16):
+        check(lib.cpt_scene_object_set_material(self.h, index, np.ascontiguousarray(material16, dtype=np.float32)))
+        return self
+
     def object_transforms(self, index):
         m = np.zeros(16, dtype=np.float32)
         inv = np.zeros(16, dtype=np.float32)
@@ -352,6 +374,11 @@ class Tracer:
     def synchronize(self):
         check(lib.cpt_tracer_synchronize(self.h))
 
+    def reduce_film(self, comm, root=0, finish=True):
+        """Sum of every rank's film (rendered with render_samples in sum mode) into `root`'s, over RCCL, on the
+        tracer's stream; with `finish` the root's film becomes the mean (alpha 1)."""
+        check(lib.cpt_tracer_reduce_film(self.h, comm.h, root, 1 if finish else 0))
+
     def render_samples(self, spp_begin, count, sum_mode=True, d_output=None, width=0, height=0):
         check(lib.cpt_tracer_render_samples(self.h, spp_begin, count, 1 if sum_mode else 0, d_output, width, height))
 
@@ -414,6 +441,102 @@ class Tracer:
         out = np.zeros(5, dtype=np.float32)
         check(lib.cpt_tracer_build_stage_ms(self.h, out.ctypes.data))
         return dict(zip(["morton", "sort", "hierarchy_workgroup", "hierarchy_memory", "reserved"], out.tolist()))
+
+
+def shard_samples(total, rank, world, first=1):
+    """(begin, count) of the block of `total` samples that shard `rank` of `world` renders."""
+    b, n = C.c_uint32(0), C.c_uint32(0)
+    check(lib.cpt_shard_samples(total, rank, world, first, C.byref(b), C.byref(n)))
+    return int(b.value), int(n.value)
+
+
+class Comm:
+    """One rank of an RCCL communicator on the current device (one process per GPU)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib.cpt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self.h = lib.cpt_comm_create(buf, rank, world)
+        if not self.h:
+            raise CptError(lib.cpt_last_error().decode("utf-8", "replace"))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.h:
+            lib.cpt_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiTracer:
+    """One render split over several shards (host thread + stream + replicated build each), summed over RCCL."""
+
+    def __init__(self, scene, width, height, shard_devices, max_depth=-1):
+        require_device()
+        self.scene = scene
+        self.width, self.height = int(width), int(height)
+        devs = (C.c_int * len(shard_devices))(*shard_devices)
+        self.h = lib.cpt_multi_create(scene.h, self.width, self.height, devs, len(shard_devices))
+        if not self.h:
+            raise CptError(lib.cpt_last_error().decode("utf-8", "replace"))
+        check(lib.cpt_multi_set_max_depth(self.h, max_depth))
+
+    def close(self):
+        if self.h:
+            lib.cpt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_integrator(self, mode):
+        check(lib.cpt_multi_set_integrator(self.h, mode))
+
+    def set_samples_per_launch(self, samples):
+        check(lib.cpt_multi_set_samples_per_launch(self.h, samples))
+
+    def build_buffers(self):
+        check(lib.cpt_multi_build_buffers(self.h))
+        return self
+
+    def render(self, total_spp):
+        """Samples 1 .. total_spp of every pixel; returns the wall milliseconds of the call (reduce included)."""
+        ms = C.c_float(0.0)
+        check(lib.cpt_multi_render(self.h, total_spp, C.byref(ms)))
+        return ms.value
+
+    def film(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        check(lib.cpt_multi_film_read(self.h, out.reshape(-1)))
+        return out
+
+    def save(self, path):
+        check(lib.cpt_multi_film_save(self.h, os.fsencode(path)))
+
+    def counters(self):
+        out = np.zeros(6, dtype=np.uint64)
+        check(lib.cpt_multi_counters(self.h, out.ctypes.data))
+        return dict(rays=int(out[0]), node_visits=int(out[1]), tri_tests=int(out[2]), paths=int(out[3]), shades=int(out[4]),
+                    stack_overflows=int(out[5]))
+
+    def reset_counters(self):
+        check(lib.cpt_multi_reset_counters(self.h))
+
+    def num_devices(self):
+        return lib.cpt_multi_num_devices(self.h)
 
 
 def write_exr(path, rgba):

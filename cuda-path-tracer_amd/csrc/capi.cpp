@@ -9,6 +9,7 @@
 
 #include "host/film.hpp"
 #include "host/loader.hpp"
+#include "host/multi_gpu.hpp"
 #include "host/pathtracer.hpp"
 #include "host/scene.hpp"
 #include "lbvh.h"
@@ -48,6 +49,16 @@ struct cpt_tracer {
     cpt_scene *owner;
     std::unique_ptr<Film> film;
     std::unique_ptr<PathTracer> tracer;
+};
+
+struct cpt_comm {
+    std::unique_ptr<cpt::ShardComm> comm;
+};
+
+struct cpt_multi {
+    cpt_scene *owner;
+    std::unique_ptr<Film> film;
+    std::unique_ptr<MultiPathTracer> tracer;
 };
 
 struct cpt_builder {
@@ -307,6 +318,22 @@ int cpt_scene_object_set_trs(cpt_scene *s, uint32_t index, const float translate
     return CPT_OK;
 }
 
+int cpt_scene_object_set_material(cpt_scene *s, uint32_t index, const float material16[16]) {
+    SceneObject *obj = s ? MeshObject(s, index) : nullptr;
+    if (!obj || !material16) return Fail(CPT_ERR_INVALID, "cpt_scene_object_set_material: no such object or null argument");
+    Material *mat = obj->GetComponent<MaterialComponent>()->GetMaterial();
+    mat->emission = cpt::V3{material16[0], material16[1], material16[2]};
+    mat->diffuse = cpt::V3{material16[3], material16[4], material16[5]};
+    mat->specular = cpt::V3{material16[6], material16[7], material16[8]};
+    mat->transmittance = cpt::V3{material16[9], material16[10], material16[11]};
+    mat->shininess = material16[12];
+    mat->ior = material16[13];
+    mat->opacity = material16[14];
+    mat->bsdf_type = (int)material16[15];
+    mat->SetChanged();
+    return CPT_OK;
+}
+
 int cpt_scene_object_transforms(const cpt_scene *s, uint32_t index, float transform16[16], float inverse16[16]) {
     SceneObject *obj = s ? MeshObject(s, index) : nullptr;
     if (!obj) return Fail(CPT_ERR_INVALID, "cpt_scene_object_transforms: no such object");
@@ -499,6 +526,118 @@ int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]) {
     memcpy(out5, t->tracer->BuildStageMs(), 5 * sizeof(float));
     return CPT_OK;
 }
+
+// ------------------------------------------------------------------ several GPUs
+int cpt_shard_samples(uint32_t total, uint32_t rank, uint32_t world, uint32_t first, uint32_t *begin, uint32_t *count) {
+    if (!begin || !count || world == 0 || rank >= world || first == 0) return Fail(CPT_ERR_INVALID, "cpt_shard_samples: bad argument");
+    const cpt::SampleBlock b = cpt::split_samples(total, rank, world, first);
+    *begin = b.begin;
+    *count = b.count;
+    return CPT_OK;
+}
+
+int cpt_comm_unique_id(uint8_t id[128]) {
+    if (!id) return Fail(CPT_ERR_INVALID, "cpt_comm_unique_id: null argument");
+    return Guard([&] {
+        auto v = cpt::ShardComm::UniqueId();
+        memcpy(id, v.data(), v.size());
+        return CPT_OK;
+    });
+}
+
+cpt_comm *cpt_comm_create(const uint8_t id[128], int rank, int world) {
+    if (!id) { Fail(CPT_ERR_INVALID, "cpt_comm_create: null id"); return nullptr; }
+    cpt_comm *c = nullptr;
+    int rc = Guard([&] {
+        std::array<char, cpt::kCommIdBytes> v;
+        memcpy(v.data(), id, v.size());
+        auto comm = cpt::ShardComm::InitRank(v, rank, world);
+        c = new cpt_comm{std::move(comm)};
+        return CPT_OK;
+    });
+    return rc == CPT_OK ? c : nullptr;
+}
+
+void cpt_comm_destroy(cpt_comm *c) { delete c; }
+
+int cpt_tracer_reduce_film(cpt_tracer *t, cpt_comm *c, int root, int finish) {
+    TRACER_OR_FAIL(t);
+    if (!c || root < 0 || root >= c->comm->World()) return Fail(CPT_ERR_INVALID, "cpt_tracer_reduce_film: bad communicator or root");
+    return Guard([&] { cpt::ReduceFilmToRoot(*t->tracer, *t->film, *c->comm, root, finish != 0); return CPT_OK; });
+}
+
+cpt_multi *cpt_multi_create(cpt_scene *s, uint32_t film_width, uint32_t film_height, const int *shard_devices, uint32_t num_shards) {
+    if (!s || film_width == 0 || film_height == 0 || !shard_devices || num_shards == 0) { Fail(CPT_ERR_INVALID, "cpt_multi_create: bad argument"); return nullptr; }
+    cpt_multi *m = nullptr;
+    int rc = Guard([&] {
+        auto holder = std::make_unique<cpt_multi>();
+        holder->owner = s;
+        holder->film = std::make_unique<Film>(film_width, film_height);
+        holder->tracer = std::make_unique<MultiPathTracer>(s->scene, *holder->film, std::vector<int>(shard_devices, shard_devices + num_shards));
+        m = holder.release();
+        return CPT_OK;
+    });
+    return rc == CPT_OK ? m : nullptr;
+}
+
+void cpt_multi_destroy(cpt_multi *m) {
+    if (!m) return;
+    m->tracer.reset();       // before the film its first shard renders into
+    delete m;
+}
+
+#define MULTI_OR_FAIL(m) do { if (!(m)) return Fail(CPT_ERR_INVALID, "null multi-GPU tracer"); } while (0)
+
+int cpt_multi_set_max_depth(cpt_multi *m, int max_depth) { MULTI_OR_FAIL(m); m->tracer->SetMaxDepth(max_depth); return CPT_OK; }
+int cpt_multi_set_integrator(cpt_multi *m, int mode) {
+    MULTI_OR_FAIL(m);
+    if (mode < 0 || mode > 5) return Fail(CPT_ERR_INVALID, "cpt_multi_set_integrator: mode must be 0 to 5");
+    m->tracer->SetIntegrator(mode);
+    return CPT_OK;
+}
+int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples) {
+    MULTI_OR_FAIL(m);
+    if (samples < 1 || samples > 4096) return Fail(CPT_ERR_INVALID, "cpt_multi_set_samples_per_launch: 1 to 4096");
+    m->tracer->SetSamplesPerLaunch(samples);
+    return CPT_OK;
+}
+int cpt_multi_build_buffers(cpt_multi *m) {
+    MULTI_OR_FAIL(m);
+    return Guard([&] { m->tracer->BuildBuffers(); return CPT_OK; });
+}
+int cpt_multi_render(cpt_multi *m, uint32_t total_spp, float *elapsed_ms) {
+    MULTI_OR_FAIL(m);
+    return Guard([&] {
+        m->tracer->Render(total_spp);
+        if (elapsed_ms) *elapsed_ms = m->tracer->LastRenderMs();
+        return CPT_OK;
+    });
+}
+int cpt_multi_film_read(cpt_multi *m, float *rgba) {
+    MULTI_OR_FAIL(m);
+    if (!rgba) return Fail(CPT_ERR_INVALID, "cpt_multi_film_read: null buffer");
+    return Guard([&] { m->tracer->Synchronize(); m->film->ReadBack(rgba); return CPT_OK; });
+}
+int cpt_multi_film_save(cpt_multi *m, const char *path) {
+    MULTI_OR_FAIL(m);
+    if (!path) return Fail(CPT_ERR_INVALID, "cpt_multi_film_save: null path");
+    return Guard([&] { m->tracer->Synchronize(); return m->film->SaveTo(path) ? CPT_OK : Fail(CPT_ERR_IO, std::string("cannot write '") + path + "'"); });
+}
+int cpt_multi_counters(cpt_multi *m, uint64_t out6[6]) {
+    MULTI_OR_FAIL(m);
+    if (!out6) return Fail(CPT_ERR_INVALID, "cpt_multi_counters: null argument");
+    return Guard([&] {
+        unsigned long long c[6];
+        m->tracer->ReadCounters(c);
+        for (int i = 0; i < 6; i++) out6[i] = c[i];
+        return CPT_OK;
+    });
+}
+int cpt_multi_reset_counters(cpt_multi *m) {
+    MULTI_OR_FAIL(m);
+    return Guard([&] { m->tracer->ResetCounters(); return CPT_OK; });
+}
+uint32_t cpt_multi_num_devices(const cpt_multi *m) { return m ? (uint32_t)m->tracer->NumDevices() : 0; }
 
 int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches) {
     if (!mismatches) return Fail(CPT_ERR_INVALID, "cpt_selftest_division: null argument");

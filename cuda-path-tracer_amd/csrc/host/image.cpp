@@ -94,6 +94,9 @@ std::shared_ptr<Image> DecodePng(const std::vector<uint8_t> &file, std::string &
     const size_t bits_per_pixel = (size_t)channels * depth;
     const size_t stride = ((size_t)width * bits_per_pixel + 7) / 8;
     const size_t bpp = bits_per_pixel >= 8 ? bits_per_pixel / 8 : 1;
+    // zlib expands by at most about 1032 : 1, so a header that announces more pixels than the compressed data can
+    // hold is damaged; refuse it before it sizes an allocation
+    if (width == 0 || height == 0 || (stride + 1) * (uint64_t)height > 1040ull * idat.size() + 4096) { error = "PNG header does not match its image data"; return nullptr; }
     std::vector<uint8_t> raw((stride + 1) * (size_t)height);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { error = "PNG image data does not inflate"; return nullptr; }

@@ -765,6 +765,7 @@ bool LoadXmlScene(Scene &scene, const std::filesystem::path &path) {
         if (it != radiance_map.end()) {
             mat->emission = it->second;
             mat->emission_map.clear();
+            mat->emission_image.reset();          // the constant replaces the map, as emission_map.reset() does at src/scene/loader.cpp:353
             mat->SetChanged();
         }
     });

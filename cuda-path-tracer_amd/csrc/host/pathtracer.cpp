@@ -32,17 +32,7 @@ void PathTracer::BuildBuffers() {
     if (!stream_) CPT_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     BuildAccel();
 
-    // src/scene/camera.cpp:28-50
-    has_camera_ = false;
-    scene_.ForEach<CameraComponent>([this](CameraComponent &camera) {
-        V3 frame_z = cpt::normalize(camera.pos - camera.look_at);
-        V3 frame_x = cpt::normalize(cpt::cross(camera.up, frame_z));
-        V3 frame_y = cpt::normalize(cpt::cross(frame_z, frame_x));
-        float radians = (camera.fov * 0.5f) * 0.01745329251994329576923690768489f;
-        float scale = std::tan(radians) * 2.0f;
-        scene_dev_.camera = cpt::CameraDev{camera.pos, frame_x, frame_y, frame_z, V3{scale, 0.0f, 0.0f}, V3{0.0f, scale, 0.0f}};
-        has_camera_ = true;
-    });
+    has_camera_ = CameraFromScene(scene_dev_.camera);
 
     BuildInstancesAndLights();
     // about 7 MB of node and triangle records: beyond that the BVH no longer lives in the caches next to the CUs
@@ -54,6 +44,56 @@ void PathTracer::BuildBuffers() {
     scene_dev_.large_scene = dense ? 1 : 0;
     CPT_HIP(hipStreamSynchronize(stream_));
     built_ = true;
+}
+
+// src/scene/camera.cpp:28-50 (CameraComponent::BuildBuffer); the last camera of the scene wins, as the reference's
+// per-component buffers would leave it
+bool PathTracer::CameraFromScene(cpt::CameraDev &out) {
+    bool found = false;
+    scene_.ForEach<CameraComponent>([&](CameraComponent &camera) {
+        V3 frame_z = cpt::normalize(camera.pos - camera.look_at);
+        V3 frame_x = cpt::normalize(cpt::cross(camera.up, frame_z));
+        V3 frame_y = cpt::normalize(cpt::cross(frame_z, frame_x));
+        float radians = (camera.fov * 0.5f) * 0.01745329251994329576923690768489f;
+        float scale = std::tan(radians) * 2.0f;
+        out = cpt::CameraDev{camera.pos, frame_x, frame_y, frame_z, V3{scale, 0.0f, 0.0f}, V3{0.0f, scale, 0.0f}};
+        found = true;
+    });
+    return found;
+}
+
+// What the reference's panels do after an edit (src/scene/material.cpp:94-100: Material::SetChanged re-uploads the
+// material's device block; src/scene/camera.cpp:19-25: CameraComponent::BuildBuffer re-uploads the camera) followed by
+// PathTracer::ResetAccumelation.  Here the tracer looks for edits itself before it renders: a material whose
+// revision moved gets its parameter block rebuilt, a camera whose values moved is re-derived, and either restarts
+// the accumulation.  As in the reference, the light table is not remade (an edit does not turn an object into a
+// light or back; BuildBuffers does).
+bool PathTracer::RefreshEdits() {
+    bool changed = false;
+    cpt::CameraDev camera = scene_dev_.camera;
+    if (CameraFromScene(camera) && memcmp(&camera, &scene_dev_.camera, sizeof(camera)) != 0) {
+        scene_dev_.camera = camera;
+        changed = true;
+    }
+    bool material_moved = false;
+    for (const MaterialEntry &m : material_entries_) material_moved |= m.material->revision != m.revision;
+    if (material_moved) {
+        std::vector<cpt::BsdfDev> blocks;
+        for (MaterialEntry &m : material_entries_) {
+            const Material *mat = m.material.get();
+            blocks.push_back(cpt::make_bsdf(mat->emission, mat->diffuse, mat->specular, mat->transmittance, mat->shininess, mat->ior, mat->opacity, mat->bsdf_type,
+                                            m.tex[0], m.tex[1], m.tex[2]));
+            m.revision = mat->revision;
+        }
+        CPT_HIP(hipStreamSynchronize(stream_));          // no kernel reads the table while it is rewritten
+        material_table_.SetData(blocks.data(), sizeof(cpt::BsdfDev) * blocks.size(), stream_);
+        changed = true;
+    }
+    if (changed) {
+        ResetAccumelation();
+        film_.Clear(stream_);
+    }
+    return changed;
 }
 
 // src/pathtracer/pathtracer.cpp:91-166 and src/scene/mesh.cpp:84-149
@@ -168,6 +208,7 @@ void PathTracer::BuildInstancesAndLights() {
     std::vector<cpt::BsdfDev> materials;
     std::vector<uint32_t> lights;
     std::unordered_map<const Material *, uint32_t> material_index;
+    material_entries_.clear();
     uint32_t slot = 0;
     // one device texture per distinct image, numbered from 1
     std::vector<const Image *> images;
@@ -188,9 +229,10 @@ void PathTracer::BuildInstancesAndLights() {
         auto found = material_index.find(mat);
         if (found == material_index.end()) {
             found = material_index.emplace(mat, (uint32_t)materials.size()).first;
+            MaterialEntry entry{material.Shared(), mat->revision, {texture_number(mat->diffuse_image), texture_number(mat->specular_image), texture_number(mat->emission_image)}};
             materials.push_back(cpt::make_bsdf(mat->emission, mat->diffuse, mat->specular, mat->transmittance, mat->shininess, mat->ior, mat->opacity,
-                                               mat->bsdf_type, texture_number(mat->diffuse_image), texture_number(mat->specular_image),
-                                               texture_number(mat->emission_image)));
+                                               mat->bsdf_type, entry.tex[0], entry.tex[1], entry.tex[2]));
+            material_entries_.push_back(std::move(entry));
         }
         cpt::InstanceDev inst;
         memset(&inst, 0, sizeof(inst));
@@ -253,6 +295,7 @@ void PathTracer::ResetAccumelation() { curr_spp_ = 0; }
 // src/pathtracer/pathtracer.cpp:26-61
 void PathTracer::Update() {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
+    RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
         last_width_ = film_.Width();
@@ -275,6 +318,7 @@ void PathTracer::Update() {
 // that: a launch's start and the tail of its longest paths cost about as much as a third of a 1024 x 1024 sample.
 void PathTracer::UpdateMany(uint32_t count) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty() || count == 0) return;
+    RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
         last_width_ = film_.Width();
@@ -394,6 +438,7 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
 
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
+    RefreshEdits();
     cpt::RenderParams p;
     p.output = output ? output : film_.DeviceMap(stream_);
     p.width = output ? width : film_.Width();

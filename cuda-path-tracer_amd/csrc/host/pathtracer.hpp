@@ -35,7 +35,9 @@ public:
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
-    // 2: wavefront (ray queues in HBM, one kernel sequence per bounce); 3: 0 or 2 by the number of triangles
+    // 2: wavefront (ray queues in HBM, one kernel sequence per bounce); 4: persistent megakernel that keeps traversal
+    // state across shading; 5: persistent megakernel whose finished lanes walk pooled shadow rays; 3: 4 or 5 by the
+    // number of triangles (4 from 65,536 on)
     void SetIntegrator(int mode) { integrator_ = mode; }
     // wavefront only: queue bounces before the persistent finishing launch; negative = queues only
     void SetWavefrontTail(int bounces) { wavefront_tail_ = bounces; }
@@ -65,9 +67,17 @@ public:
     void SetProfileBuild(bool on) { profile_build_ = on; }
     const float *BuildStageMs() const { return build_stage_ms_; }
 
+    // Looks for edits made to the scene's materials (Material::SetChanged) and camera since the device tables were
+    // written, re-uploads what moved and restarts the accumulation; Update and UpdateMany call it.  Returns whether
+    // anything had changed.
+    bool RefreshEdits();
+
 private:
     void BuildAccel();
     void BuildInstancesAndLights();
+    bool CameraFromScene(cpt::CameraDev &out);
+    struct MaterialEntry { std::shared_ptr<Material> material; uint32_t revision; uint32_t tex[3]; };
+    std::vector<MaterialEntry> material_entries_;        // in material-table order
 
     struct MeshBuffers {
         cpt::HipBuffer positions, normals, texcoords, indices;

@@ -85,6 +85,7 @@ class MaterialComponent {
 public:
     void SetMaterial(std::shared_ptr<Material> material) { material_ = std::move(material); }
     Material *GetMaterial() const { return material_.get(); }
+    const std::shared_ptr<Material> &Shared() const { return material_; }
 private:
     std::shared_ptr<Material> material_;
 };

@@ -43,6 +43,14 @@ struct Reader {
     bool ok = true;
     void Bytes(void *p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
     template <typename T> T Pod() { T v{}; Bytes(&v, sizeof(T)); return v; }
+    // bytes between the read position and the end of the file (0 when that cannot be told)
+    uint64_t Remaining() {
+        const long here = ftell(f);
+        if (here < 0 || fseek(f, 0, SEEK_END) != 0) return 0;
+        const long end = ftell(f);
+        if (fseek(f, here, SEEK_SET) != 0 || end < here) { ok = false; return 0; }
+        return (uint64_t)(end - here);
+    }
     std::string String() {
         const uint32_t n = Pod<uint32_t>();
         if (!ok || n > (1u << 20)) { ok = false; return {}; }
@@ -96,6 +104,8 @@ bool ReadCache(Scene &scene, const fs::path &cache, const fs::path &obj, int bsd
         o.material = r.Pod<uint32_t>();
         const uint64_t nv = r.Pod<uint64_t>(), ni = r.Pod<uint64_t>();
         if (!r.ok || o.material >= num_materials || nv > 0xffffffffull || ni > (1ull << 40) || ni % 3 != 0) return false;
+        // a damaged count must not size an allocation: the arrays it announces have to be in the file
+        if (nv * (2 * sizeof(cpt::V3) + sizeof(cpt::V2)) + ni * sizeof(uint32_t) > r.Remaining()) return false;
         o.positions.resize(nv); o.normals.resize(nv); o.texcoords.resize(nv); o.indices.resize(ni);
         r.Bytes(o.positions.data(), nv * sizeof(cpt::V3));
         r.Bytes(o.normals.data(), nv * sizeof(cpt::V3));

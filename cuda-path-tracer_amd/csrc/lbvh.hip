@@ -891,8 +891,12 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     uint32_t *tile_status = tickets + 64;                              // kPasses x tiles x kBins
     const size_t sort_ctl_bytes = 4 * ((size_t)kPasses * kBins + 64 + (size_t)kPasses * tiles * kBins);
 
-    hipEvent_t ev[6];
-    if (stage_ms) for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+    struct StageEvents {                        // destroyed on every way out of this function
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~StageEvents() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+    } stage_events;
+    hipEvent_t *ev = stage_events.ev;
+    if (stage_ms) for (int i = 0; i < 6; i++) HIP_OK(hipEventCreate(&ev[i]));
     auto mark = [&](int i) { if (stage_ms) (void)hipEventRecord(ev[i], stream); };
 
     const uint32_t grid_n = cdiv(n, kBlock);
@@ -965,18 +969,20 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     }
     mark(4);
     mark(5);
-    if (keys_out) HIP_OK(hipMemcpyAsync(keys_out, src, 8 * (size_t)n, hipMemcpyDeviceToDevice, stream));
-    HIP_OK(hipGetLastError());
+    int copy_status = keys_out ? (int)hipMemcpyAsync(keys_out, src, 8 * (size_t)n, hipMemcpyDeviceToDevice, stream) : 0;
+    // The look-back sort reports a predecessor tile it gave up waiting for through a flag; a build that used it
+    // always reads the flag back (and so waits for the build), a silently incomplete scatter is never returned.
     uint32_t sort_failed = 0;
-    if (stage_ms || !ws_in) {
-        if (onesweep) HIP_OK(hipMemcpyAsync(&sort_failed, tickets + 8, 4, hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+    int status = copy_status ? copy_status : (int)hipGetLastError();
+    if (status == 0 && (stage_ms || !ws_in || onesweep)) {
+        if (onesweep) status = (int)hipMemcpyAsync(&sort_failed, tickets + 8, 4, hipMemcpyDeviceToHost, stream);
+        if (status == 0) status = (int)hipStreamSynchronize(stream);
     }
     if (stage_ms) {
-        for (int i = 0; i < 5; i++) HIP_OK(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]));
-        for (auto &e : ev) (void)hipEventDestroy(e);
+        for (int i = 0; i < 5 && status == 0; i++) status = (int)hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]);
     }
     if (!ws_in) local.release();                // the temporaries die with this call, as in the reference
+    if (status) return status;
     return sort_failed ? (int)hipErrorLaunchFailure : 0;
 }
 

@@ -515,7 +515,36 @@ __global__ void __launch_bounds__(256) k_stream_copy(const RawF4 *__restrict__ s
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
 }
 
+// d_dst += d_src, one float4 (pixel) per lane and trip
+__global__ void __launch_bounds__(256) k_film_add(RawF4 *__restrict__ dst, const RawF4 *__restrict__ src, unsigned long long pixels) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < pixels; i += stride) dst[i] = dst[i] + src[i];
+}
+
+// sums with the sample count in alpha -> mean radiance, alpha 1 (a pixel without samples stays as it is)
+__global__ void __launch_bounds__(256) k_film_finish(RawF4 *__restrict__ film, unsigned long long pixels) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < pixels; i += stride) {
+        RawF4 v = film[i];
+        if (v.w > 0.0f) film[i] = RawF4{v.x / v.w, v.y / v.w, v.z / v.w, 1.0f};
+    }
+}
+
 }  // namespace
+
+int launch_film_add(float *dst, const float *src, uint64_t pixels, hipStream_t stream) {
+    if (pixels == 0) return 0;
+    const unsigned long long want = (pixels + 255) / 256;
+    hipLaunchKernelGGL(k_film_add, dim3((uint32_t)(want > 8192 ? 8192 : want)), dim3(256), 0, stream, (RawF4 *)dst, (const RawF4 *)src, (unsigned long long)pixels);
+    return (int)hipGetLastError();
+}
+
+int launch_film_finish(float *film, uint64_t pixels, hipStream_t stream) {
+    if (pixels == 0) return 0;
+    const unsigned long long want = (pixels + 255) / 256;
+    hipLaunchKernelGGL(k_film_finish, dim3((uint32_t)(want > 8192 ? 8192 : want)), dim3(256), 0, stream, (RawF4 *)film, (unsigned long long)pixels);
+    return (int)hipGetLastError();
+}
 
 int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t stream) {
     const unsigned long long n16 = bytes / 16;

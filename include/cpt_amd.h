@@ -112,6 +112,12 @@ int cpt_scene_set_camera(cpt_scene *s, const float pos[3], const float look_at[3
  * (src/scene/core.hpp:232-234); the transform is T * Rz * Ry * Rx * S (src/scene/core.cpp:109-117).
  * Takes effect at the next cpt_tracer_build_buffers. */
 int cpt_scene_object_set_trs(cpt_scene *s, uint32_t index, const float translate[3], const float rotate_degrees[3], const float scale[3]);
+/* Edits the material of mesh object `index` (shared by every object that uses it) the way the reference's material
+ * panel does (src/scene/material.cpp:60-100: new values, then SetChanged).  A tracer built on the scene notices the
+ * edit at its next update, re-uploads the material's parameter block and restarts its accumulation; a moved camera
+ * (cpt_scene_set_camera, src/scene/camera.cpp:11-25) is picked up the same way.  Which objects are lights is decided
+ * by cpt_tracer_build_buffers, not by an edit. */
+int cpt_scene_object_set_material(cpt_scene *s, uint32_t index, const float material16[16]);
 /* the object's transform and the inverse the path tracer stores with it (src/pathtracer/pathtracer.cpp:110-114),
  * column major; either pointer may be NULL */
 int cpt_scene_object_transforms(const cpt_scene *s, uint32_t index, float transform16[16], float inverse16[16]);
@@ -202,6 +208,48 @@ int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]);
 int cpt_tracer_stack_overflows(cpt_tracer *t, uint64_t *count);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
+
+/* ---- several GPUs of one node -----------------------------------------------------------------
+ * No counterpart in the reference, which renders on one GPU (nothing under src/ selects a device).  The sampler is
+ * seeded from the pixel index and the 1-based sample number (src/kernels/integrator/path.cu:92), so a render's
+ * samples split into disjoint blocks; every GPU holds the whole scene and its BVH, renders its block as sums and one
+ * sum-reduce of the W*H*4 floats over RCCL (xGMI) to the root, followed by a division by the sample count, gives the
+ * image.  librccl is opened at the first call of this section, not when the library is loaded.
+ *
+ * cpt_shard_samples: the block [*begin, *begin + *count) of `total` samples starting at the 1-based index `first`
+ * that shard `rank` of `world` renders (contiguous, in rank order, remainder to the lowest ranks). */
+int cpt_shard_samples(uint32_t total, uint32_t rank, uint32_t world, uint32_t first, uint32_t *begin, uint32_t *count);
+
+/* One process per GPU (a launcher such as torchrun): rank 0 calls cpt_comm_unique_id and hands the 128 bytes to every
+ * process by its own means; each process makes its rank with its GPU current (cpt_set_device), renders its block with
+ * cpt_tracer_render_samples(t, begin, count, 1, NULL, 0, 0) into a cleared film (cpt_tracer_reset_accumulation) and
+ * calls cpt_tracer_reduce_film: in-place ncclReduce(sum) of the film to `root` on the tracer's stream and, with
+ * `finish`, division by the sample count on the root (alpha becomes 1).  Asynchronous; cpt_tracer_synchronize waits. */
+typedef struct cpt_comm cpt_comm;
+int cpt_comm_unique_id(uint8_t id[128]);
+cpt_comm *cpt_comm_create(const uint8_t id[128], int rank, int world);       /* collective over all ranks; NULL on failure */
+void cpt_comm_destroy(cpt_comm *c);
+int cpt_tracer_reduce_film(cpt_tracer *t, cpt_comm *c, int root, int finish);
+
+/* One process, one host thread per shard (what `cuda-pathtracer --gpus N` runs): shard i renders on HIP device
+ * shard_devices[i] with its own stream, film and replicated build.  A device may be named more than once; its shards
+ * are summed on the device before the reduce between devices.  cpt_multi_render renders samples 1 .. total_spp split
+ * over the shards, reduces to shard 0 and leaves the mean (alpha 1) in the film; elapsed_ms (optional) receives the
+ * wall time of the call, reduce included.  Counters are summed over shards: rays, node records, triangle records,
+ * paths, shading surfaces, dropped stack entries. */
+typedef struct cpt_multi cpt_multi;
+cpt_multi *cpt_multi_create(cpt_scene *s, uint32_t film_width, uint32_t film_height, const int *shard_devices, uint32_t num_shards);
+void cpt_multi_destroy(cpt_multi *m);
+int cpt_multi_set_max_depth(cpt_multi *m, int max_depth);
+int cpt_multi_set_integrator(cpt_multi *m, int mode);
+int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples);
+int cpt_multi_build_buffers(cpt_multi *m);
+int cpt_multi_render(cpt_multi *m, uint32_t total_spp, float *elapsed_ms);
+int cpt_multi_film_read(cpt_multi *m, float *rgba);
+int cpt_multi_film_save(cpt_multi *m, const char *path);
+int cpt_multi_counters(cpt_multi *m, uint64_t out6[6]);
+int cpt_multi_reset_counters(cpt_multi *m);
+uint32_t cpt_multi_num_devices(const cpt_multi *m);                           /* distinct GPUs = ranks of the reduce */
 
 /* Device self-test: the traversal divides by a ray direction through a reciprocal-based sequence
  * that must equal the correctly rounded quotient bit for bit; this runs at least `pairs` operand

@@ -364,3 +364,69 @@ def test_wavefront_sum_mode_and_normal_channel(cpt):
     for k in (1, 2, 3):
         assert np.array_equal(out[0][0].view(np.uint32), out[k][0].view(np.uint32))
         assert np.array_equal(out[0][1].view(np.uint32), out[k][1].view(np.uint32))
+
+
+def test_render_through_an_xml_scene(cpt, tmp_path):
+    """The .xml path end to end on the GPU (/root/reference/src/scene/loader.cpp:296-359): camera block, a radiance
+    that replaces the light's Ke, against the oracle fed with the same numbers."""
+    d = os.path.join(SCENES, "cornell-box-glass")
+    x = tmp_path / "scene.xml"
+    x.write_text('<?xml version="1.0" encoding="utf-8"?>\n<camera type="perspective" width="80" height="60" fovy="21.5">\n'
+                 '  <eye x="6.5" y="1.1" z="0.1"/>\n  <lookat x="0" y="1" z="0"/>\n  <up x="0" y="1" z="0"/>\n</camera>\n'
+                 '<light mtlname="light" radiance="30.0, 9.0, 21.0"/>\n')
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_xml(str(x))
+    c = sc.camera()
+    assert (c["width"], c["height"]) == (80, 60)
+    tr = cpt.Tracer(sc, 80, 60, max_depth=6).build_buffers()
+    tr.update(16)
+    img = tr.film()
+    objs, _ = cornell(glass=True)
+    for o in objs:
+        if o["material_name"] == "light":
+            o["material"] = o["material"].copy()
+            o["material"][0:3] = [30.0, 9.0, 21.0]
+    cam = dict(pos=np.float32([6.5, 1.1, 0.1]), look_at=np.float32([0, 1, 0]), up=np.float32([0, 1, 0]), fov=21.5)
+    ref, _ = OracleScene(objs, cam).render(80, 60, 1, 17, 6)
+    compare(img, ref)
+    assert img[..., 0].mean() > 2.0 * img[..., 1].mean()          # the overriding radiance is what lights the scene
+    # the executable on the same files
+    out = tmp_path / "xml"
+    r = subprocess.run([BINARY, os.path.join(d, "cornell-box.obj"), str(x), "--ui", "0", "--max-depth", "6", "--max-spp", "16", "-o", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(parse_exr(str(out) + ".exr")[0].view(np.uint32), img.view(np.uint32))
+
+
+def test_material_and_camera_edits_restart_the_render(cpt):
+    """An edited material (Material::SetChanged, /root/reference/src/scene/material.cpp:94-100) or a moved camera
+    (src/scene/camera.cpp:19-25) reaches the device at the next update, which starts the accumulation again: the
+    film then equals that of a tracer built on the edited scene from the start, bit for bit."""
+    objs, cam = cornell(glass=True)
+    sc, tr = gpu_scene(cpt, objs, cam, 64, 64, max_depth=5)
+    tr.update(5)
+    before = tr.film()
+    red = [i for i, o in enumerate(objs) if o["material_name"] == "red"][0]
+    edited = objs[red]["material"].copy()
+    edited[3:6] = [0.1, 0.2, 0.9]
+    sc.set_material(red, edited)
+    tr.update(4)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 4
+    after = tr.film()
+    assert not np.array_equal(after, before) and np.all(after[..., 3] == 1.0)
+    objs2 = [dict(o) for o in objs]
+    objs2[red]["material"] = edited
+    _, fresh = gpu_scene(cpt, objs2, cam, 64, 64, max_depth=5)
+    fresh.update(4)
+    assert np.array_equal(after.view(np.uint32), fresh.film().view(np.uint32))
+    ref, _ = OracleScene(objs2, cam).render(64, 64, 1, 5, 5)
+    compare(after, ref)
+    # camera
+    moved = dict(cam, pos=np.float32([6.0, 1.2, 0.3]))
+    sc.set_camera(moved["pos"], moved["look_at"], moved["up"], moved["fov"], 64, 64)
+    tr.update(3)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 3
+    ref, _ = OracleScene(objs2, moved).render(64, 64, 1, 4, 5)
+    compare(tr.film(), ref)
+    # no edit: the accumulation goes on
+    tr.update(2)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 5
