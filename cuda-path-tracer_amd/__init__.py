@@ -73,6 +73,7 @@ _sig("cpt_tracer_destroy", None, [_vp])
 _sig("cpt_tracer_set_max_depth", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_channel", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_integrator", C.c_int, [_vp, C.c_int])
+_sig("cpt_tracer_set_traversal", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_wavefront_tail", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
@@ -107,6 +108,7 @@ _sig("cpt_multi_create", _vp, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32])
 _sig("cpt_multi_destroy", None, [_vp])
 _sig("cpt_multi_set_max_depth", C.c_int, [_vp, C.c_int])
 _sig("cpt_multi_set_integrator", C.c_int, [_vp, C.c_int])
+_sig("cpt_multi_set_traversal", C.c_int, [_vp, C.c_int])
 _sig("cpt_multi_set_samples_per_launch", C.c_int, [_vp, C.c_uint32])
 _sig("cpt_multi_build_buffers", C.c_int, [_vp])
 _sig("cpt_multi_render", C.c_int, [_vp, C.c_uint32, _vp])
@@ -333,6 +335,10 @@ class Tracer:
     def set_integrator(self, mode):
         check(lib.cpt_tracer_set_integrator(self.h, mode))
 
+    def set_traversal(self, mode):
+        """0 exact (the reference's order and arithmetic, bit-exact), 1 fast (ordered traversal)."""
+        check(lib.cpt_tracer_set_traversal(self.h, mode))
+
     def set_wavefront_tail(self, bounces):
         check(lib.cpt_tracer_set_wavefront_tail(self.h, bounces))
 
@@ -504,6 +510,9 @@ class MultiTracer:
 
     def set_integrator(self, mode):
         check(lib.cpt_multi_set_integrator(self.h, mode))
+
+    def set_traversal(self, mode):
+        check(lib.cpt_multi_set_traversal(self.h, mode))
 
     def set_samples_per_launch(self, samples):
         check(lib.cpt_multi_set_samples_per_launch(self.h, samples))

@@ -391,6 +391,12 @@ int cpt_tracer_set_integrator(cpt_tracer *t, int mode) {
     t->tracer->SetIntegrator(mode);
     return CPT_OK;
 }
+int cpt_tracer_set_traversal(cpt_tracer *t, int mode) {
+    TRACER_OR_FAIL(t);
+    if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_traversal: 0 (exact) or 1 (fast)");
+    t->tracer->SetTraversal(mode);
+    return CPT_OK;
+}
 int cpt_tracer_set_wavefront_tail(cpt_tracer *t, int bounces) { TRACER_OR_FAIL(t); t->tracer->SetWavefrontTail(bounces); return CPT_OK; }
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on) { TRACER_OR_FAIL(t); t->tracer->SetProfileBuild(on != 0); return CPT_OK; }
 int cpt_tracer_build_buffers(cpt_tracer *t) {
@@ -593,6 +599,12 @@ int cpt_multi_set_integrator(cpt_multi *m, int mode) {
     MULTI_OR_FAIL(m);
     if (mode < 0 || mode > 5) return Fail(CPT_ERR_INVALID, "cpt_multi_set_integrator: mode must be 0 to 5");
     m->tracer->SetIntegrator(mode);
+    return CPT_OK;
+}
+int cpt_multi_set_traversal(cpt_multi *m, int mode) {
+    MULTI_OR_FAIL(m);
+    if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_multi_set_traversal: 0 (exact) or 1 (fast)");
+    m->tracer->SetTraversal(mode);
     return CPT_OK;
 }
 int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples) {

@@ -62,7 +62,7 @@ struct InstanceDev {
     uint32_t mesh;
     uint32_t material;
     int32_t light;       // index into the light table or -1
-    uint32_t pad;
+    uint32_t tlas_position;  // position of the instance among the sorted leaves of the top-level BVH (the reference visits leaves in descending position)
 };
 
 enum BsdfType : int { kLambert = 0, kPhong = 1, kBlinnPhong = 2, kMicrofacet = 3, kGlass = 4 };   // src/kernels/bsdf/bsdf.cuh:14-20
@@ -120,6 +120,7 @@ struct SceneDev {
     float light_pick_pdf;
     CameraDev camera;
     Counters *counters;         // kCounterSlots slots; may be null
+    int fast_traversal;         // 0: the reference's traversal order and arithmetic (bit-exact results); 1: ordered traversal (trace.h)
     int large_scene;            // the BVH is far larger than the caches next to the CUs: batch queries use the kernel builds for such scenes
 };
 

@@ -16,6 +16,7 @@ struct Flow {
     uint32_t cur = kNoNode;
     uint32_t sp = 0, sp_base = 0, inst_id = 0;
     bool in_blas = false, found = false, world_fast = false;
+    uint32_t inst_pos = 0, hit_pos = 0, hit_slot = 0;   // ordered traversal: top-level leaf position of the instance being walked; of the hit held; its sorted-leaf slot
     float tmax = 0.0f;
     V3 world_r = v3(0.0f);
     RayFrame f;
@@ -28,15 +29,16 @@ struct Flow {
     // What a ray needs before its first trip: the reciprocal direction (when the fast division applies)
     // and the test of the top-level root box, which AccelTop::Intersect / Occlude do when they pop node 0.
     struct Prepared { V3 r; bool fast, enters; };
+    template <bool FAST = false>
     static __device__ inline Prepared prepare(const SceneDev &sc, V3 ow, V3 dw, float reach) {
         const AccelRoot troot = *sc.top_root;
         RayFrame w;
-        w.set(ow, dw, troot.flags == 0);
+        w.set_for<FAST>(ow, dw, troot.flags == 0);
         float t0;
         Prepared q;
         q.r = w.r;
         q.fast = w.fast;
-        q.enters = slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], w, kRayTMin, t0) && t0 < reach;
+        q.enters = slab_of<FAST>(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], w, kRayTMin, t0) && t0 < reach;
         return q;
     }
     // Begins the ray (ow, dw) of reach `reach`; afterwards walking() is false if it missed everything at once.
@@ -58,6 +60,7 @@ struct Flow {
     // walking() false.  Returns false, in every lane, when no lane of the wave had a step to take.
     template <class Stack, class World>
     __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, World world, bool any) {
+        constexpr bool FAST = Stack::kFast;        // the ordered traversal of trace.h (Traversal), same rules
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -70,11 +73,21 @@ struct Flow {
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
                 cnt.nodes++;
                 float t0l, t0r;
-                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l);
-                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r);
-                if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
-                if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
-                else need_pop = true;
+                if constexpr (FAST) {
+                    const bool hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l) && within_reach<true>(t0l, tmax, any);
+                    const bool hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r) && within_reach<true>(t0r, tmax, any);
+                    const uint32_t lc = __float_as_uint(q3.x), rc = __float_as_uint(q3.y);
+                    const bool left_first = t0l < t0r;
+                    if (hl && hr) { st.push(sp, left_first ? rc : lc, left_first ? t0r : t0l); sp++; }
+                    if (hl || hr) cur = (hl && (left_first || !hr)) ? lc : rc;
+                    else need_pop = true;
+                } else {
+                    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l);
+                    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r);
+                    if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                    if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                    else need_pop = true;
+                }
             }
         } else if (ct >= ci) {
             if (is_tri) {
@@ -82,7 +95,23 @@ struct Flow {
                 uint32_t prim;
                 cnt.tris++;
                 need_pop = true;
-                if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
+                if constexpr (FAST) {
+                    bool tie;
+                    const uint32_t slot = cur & ~kLeafBit;
+                    if (tri_test_or_tie(tris + slot, f.o, f.d, kRayTMin, tmax, t, bv, bw, prim, tie)) {
+                        if (any) {
+                            if (!tie) { found = true; need_pop = false; cur = kNoNode; }       // any hit is strictly inside the reach (accel.cuh:96-110)
+                        } else {
+                            const bool later = inst_pos > hit_pos || (inst_pos == hit_pos && slot > hit_slot);
+                            if (!tie || !found || later) {
+                                found = true;
+                                tmax = t;
+                                hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                                hit_pos = inst_pos; hit_slot = slot;
+                            }
+                        }
+                    }
+                } else if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
                     found = true;
                     if (any) {
                         need_pop = false;
@@ -102,13 +131,14 @@ struct Flow {
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
+                if constexpr (FAST) inst_pos = in.tlas_position;
                 V3 ow, dw;
                 world(ow, dw);
-                f.set(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
+                f.set_for<FAST>(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
-                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, kRayTMin, t0) && t0 < tmax) cur = r.ref;
+                if (slab_of<FAST>(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, kRayTMin, t0) && within_reach<FAST>(t0, tmax, any)) cur = r.ref;
                 else need_pop = true;
             }
         }
@@ -119,7 +149,7 @@ struct Flow {
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);
-                if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+                if (within_reach<FAST>(__uint_as_float(e.y), tmax, any)) { cur = e.x; break; }
             }
         }
         return cn + ct + ci != 0;

@@ -230,6 +230,7 @@ void MultiPathTracer::BuildBuffers() {
         t.SetMaxDepth(max_depth_);
         t.SetIntegrator(integrator_);
         t.SetChannel(channel_);
+        t.SetTraversal(traversal_);
         t.SetSamplesPerLaunch(samples_per_launch_);
         t.SetWavefrontTail(wavefront_tail_);
         t.BuildBuffers();
@@ -253,6 +254,7 @@ void MultiPathTracer::Render(uint32_t total_spp, uint32_t first, void (*progress
         t.SetMaxDepth(max_depth_);
         t.SetIntegrator(integrator_);
         t.SetChannel(channel_);
+        t.SetTraversal(traversal_);
         t.SetSamplesPerLaunch(samples_per_launch_);
         t.SetWavefrontTail(wavefront_tail_);
         s.film->Clear(t.Stream());

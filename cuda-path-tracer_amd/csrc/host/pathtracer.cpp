@@ -250,6 +250,16 @@ void PathTracer::BuildInstancesAndLights() {
         slot++;
     });
 
+    // position of every instance among the sorted top-level leaves: the low word of sorted key k is the instance at position k
+    if (!instances.empty()) {
+        std::vector<uint64_t> sorted(instances.size());
+        CPT_HIP(hipMemcpyAsync(sorted.data(), top_keys_.GpuData(), sizeof(uint64_t) * sorted.size(), hipMemcpyDeviceToHost, stream_));
+        CPT_HIP(hipStreamSynchronize(stream_));
+        for (size_t k = 0; k < sorted.size(); k++) {
+            const uint32_t id = (uint32_t)sorted[k];
+            if (id < instances.size()) instances[id].tlas_position = (uint32_t)k;
+        }
+    }
     num_lights_ = (uint32_t)lights.size();
     if (!instances.empty()) instance_table_.Allocate(sizeof(cpt::InstanceDev) * instances.size(), instances.data(), stream_);
     if (!materials.empty()) material_table_.Allocate(sizeof(cpt::BsdfDev) * materials.size(), materials.data(), stream_);
@@ -422,15 +432,17 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         return;
     }
     const int variant = integrator == 4 ? 1 : (integrator == 5 ? 2 : 0);
-    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant) {
+    const bool fast = scene_dev_.fast_traversal != 0;
+    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_fast_ != fast) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, fast);
         resident_dense_ = wf_dense_;
         resident_variant_ = variant;
+        resident_fast_ = fast;
     }
     rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, variant, stream_), "render");
     queue_parity_ ^= 1u;

@@ -34,6 +34,12 @@ public:
 
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
+    // 0: the reference's traversal order and arithmetic, results bit for bit the reference's (default); 1: ordered
+    // traversal (nearer child first, slab distances by reciprocal multiplication): same hit distances, but among
+    // triangles at (nearly) the same distance another one may be reported.  Used by the batch queries and by
+    // integrators 4 and 5 (and 3, which picks one of them); integrators 0, 1 and 2 always run exact.
+    void SetTraversal(int mode) { scene_dev_.fast_traversal = mode ? 1 : 0; }
+    int Traversal() const { return scene_dev_.fast_traversal; }
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
     // 2: wavefront (ray queues in HBM, one kernel sequence per bounce); 4: persistent megakernel that keeps traversal
     // state across shading; 5: persistent megakernel whose finished lanes walk pooled shadow rays; 3: 4 or 5 by the
@@ -114,6 +120,7 @@ private:
     bool wf_dense_ = false;          // set by BuildBuffers from the scene's triangle count: which build of the persistent kernels runs
     bool resident_dense_ = false;
     int resident_variant_ = 0;
+    bool resident_fast_ = false;
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
 

@@ -179,13 +179,13 @@ constexpr int kFlowWaves = 4;
 #endif
 constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
-template <bool MAPS>
+template <bool MAPS, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
+    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene, FAST> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -249,13 +249,13 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
             if (!s.has_shadow && !t.walking()) { s.ext_traced = s.has_ext; s.has_ext = false; }
         };
         if (s.l.alive && !t.walking() && !s.l.film_pending) {
-            const Flow::Prepared ext = Flow::prepare(sc, s.l.ro, s.l.rd, kRayTMax);
+            const Flow::Prepared ext = Flow::prepare<FAST>(sc, s.l.ro, s.l.rd, kRayTMax);
             if (s.has_shadow) {
                 if (s.has_ext) {
                     s_next[threadIdx.x] = ext.r.x; s_next[kTraceBlock + threadIdx.x] = ext.r.y; s_next[2 * kTraceBlock + threadIdx.x] = ext.r.z;
                     s_next[3 * kTraceBlock + threadIdx.x] = __uint_as_float((ext.fast ? 1u : 0u) | (ext.enters ? 2u : 0u));
                 }
-                t.begin(sc, s.l.ro, s.shadow_dir, s.shadow_tmax, Flow::prepare(sc, s.l.ro, s.shadow_dir, s.shadow_tmax), cnt);
+                t.begin(sc, s.l.ro, s.shadow_dir, s.shadow_tmax, Flow::prepare<FAST>(sc, s.l.ro, s.shadow_dir, s.shadow_tmax), cnt);
             } else {
                 t.begin(sc, s.l.ro, s.l.rd, kRayTMax, ext, cnt);
             }
@@ -292,7 +292,7 @@ template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5
 #endif
 constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every eighth trip
 
-template <bool MAPS, bool DENSE>
+template <bool MAPS, bool DENSE, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     __shared__ float4 s_pool[4 * kTraceBlock];
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         job = 0xffffffffu;
         s.ext_traced = s.l.alive && s.has_ext;
         t = Flow();                                     // nothing of the last bounce's walks is carried over
-        if (s.ext_traced) t.begin(sc, s.l.ro, s.l.rd, kRayTMax, Flow::prepare(sc, s.l.ro, s.l.rd, kRayTMax), cnt);
+        if (s.ext_traced) t.begin(sc, s.l.ro, s.l.rd, kRayTMax, Flow::prepare<FAST>(sc, s.l.ro, s.l.rd, kRayTMax), cnt);
         bool own = s.ext_traced;                        // the ray in `t` is the lane's own extension ray
         uint32_t pool_next = 0;
 
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
             result.found = ext_found;
             result.hit = ext_hit;
             flow_shade<MAPS>(sc, p, s, result, cnt, [&](V3 pos, V3 dir, float reach, V3 contribution) {
-                const Flow::Prepared q = Flow::prepare(sc, pos, dir, reach);
+                const Flow::Prepared q = Flow::prepare<FAST>(sc, pos, dir, reach);
                 cnt.rays++;
                 if (!q.enters) { s.l.color = s.l.color + contribution; return false; }
                 s_pool[4 * threadIdx.x] = make_float4(pos.x, pos.y, pos.z, reach);
@@ -419,13 +419,13 @@ constexpr int kQueryLdsEntries = 8;
 // with 1 or 2, 2.46 with 4) while diverging ones gain (soup 1M: 0.67 with 1, 0.75 with 2, 0.81 with 4)
 constexpr int kQueryLeafWeightLargeScene = 2;
 
-template <bool LARGE>
+template <bool LARGE, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -442,12 +442,12 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
-template <bool LARGE>
+template <bool LARGE, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -580,19 +580,30 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     unsigned long long want = ((unsigned long long)tiles * p.spp_count + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;
     const dim3 grid(blocks), block(kTraceBlock);
+    const bool fast = sc.fast_traversal != 0;
     if (variant == 2) {
-        if (sc.textures) {
-            if (dense) hipLaunchKernelGGL((k_render_pool<true, true>), grid, block, 0, stream, sc, p, queue, parity);
-            else hipLaunchKernelGGL((k_render_pool<true, false>), grid, block, 0, stream, sc, p, queue, parity);
-        } else {
-            if (dense) hipLaunchKernelGGL((k_render_pool<false, true>), grid, block, 0, stream, sc, p, queue, parity);
-            else hipLaunchKernelGGL((k_render_pool<false, false>), grid, block, 0, stream, sc, p, queue, parity);
+        // kernel build by (material maps, large scene, ordered traversal)
+        const int which = (sc.textures ? 4 : 0) | (dense ? 2 : 0) | (fast ? 1 : 0);
+        switch (which) {
+            case 0: hipLaunchKernelGGL((k_render_pool<false, false, false>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 1: hipLaunchKernelGGL((k_render_pool<false, false, true>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 2: hipLaunchKernelGGL((k_render_pool<false, true, false>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 3: hipLaunchKernelGGL((k_render_pool<false, true, true>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 4: hipLaunchKernelGGL((k_render_pool<true, false, false>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 5: hipLaunchKernelGGL((k_render_pool<true, false, true>), grid, block, 0, stream, sc, p, queue, parity); break;
+            case 6: hipLaunchKernelGGL((k_render_pool<true, true, false>), grid, block, 0, stream, sc, p, queue, parity); break;
+            default: hipLaunchKernelGGL((k_render_pool<true, true, true>), grid, block, 0, stream, sc, p, queue, parity); break;
         }
         return (int)hipGetLastError();
     }
     if (variant == 1) {
-        if (sc.textures) hipLaunchKernelGGL(k_render_flow<true>, grid, block, 0, stream, sc, p, queue, parity);
-        else hipLaunchKernelGGL(k_render_flow<false>, grid, block, 0, stream, sc, p, queue, parity);
+        if (sc.textures) {
+            if (fast) hipLaunchKernelGGL((k_render_flow<true, true>), grid, block, 0, stream, sc, p, queue, parity);
+            else hipLaunchKernelGGL((k_render_flow<true, false>), grid, block, 0, stream, sc, p, queue, parity);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_render_flow<false, true>), grid, block, 0, stream, sc, p, queue, parity);
+            else hipLaunchKernelGGL((k_render_flow<false, false>), grid, block, 0, stream, sc, p, queue, parity);
+        }
         return (int)hipGetLastError();
     }
     if (sc.textures) {
@@ -605,16 +616,21 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device, bool dense, int variant) {
+int render_regen_resident_blocks(int device, bool dense, int variant, bool fast) {
     int per_cu = 0, other = 0, cus = 0;
     const void *with_maps = dense ? (const void *)k_render_regen<true, true> : (const void *)k_render_regen<true, false>;
     const void *without = dense ? (const void *)k_render_regen<false, true> : (const void *)k_render_regen<false, false>;
     if (variant == 1) {
-        with_maps = (const void *)k_render_flow<true>;
-        without = (const void *)k_render_flow<false>;
+        with_maps = fast ? (const void *)k_render_flow<true, true> : (const void *)k_render_flow<true, false>;
+        without = fast ? (const void *)k_render_flow<false, true> : (const void *)k_render_flow<false, false>;
     } else if (variant == 2) {
-        with_maps = dense ? (const void *)k_render_pool<true, true> : (const void *)k_render_pool<true, false>;
-        without = dense ? (const void *)k_render_pool<false, true> : (const void *)k_render_pool<false, false>;
+        if (fast) {
+            with_maps = dense ? (const void *)k_render_pool<true, true, true> : (const void *)k_render_pool<true, false, true>;
+            without = dense ? (const void *)k_render_pool<false, true, true> : (const void *)k_render_pool<false, false, true>;
+        } else {
+            with_maps = dense ? (const void *)k_render_pool<true, true, false> : (const void *)k_render_pool<true, false, false>;
+            without = dense ? (const void *)k_render_pool<false, true, false> : (const void *)k_render_pool<false, false, false>;
+        }
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_maps, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, without, kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
@@ -627,8 +643,14 @@ int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    if (sc.large_scene) hipLaunchKernelGGL(k_first_hit<true>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
-    else hipLaunchKernelGGL(k_first_hit<false>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, inst, prim, t, uv);
+    const dim3 grid((uint32_t)blocks), block(kTraceBlock);
+    const unsigned long long count = n;
+    switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((k_first_hit<false, false>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
+        case 1: hipLaunchKernelGGL((k_first_hit<false, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
+        case 2: hipLaunchKernelGGL((k_first_hit<true, false>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
+        default: hipLaunchKernelGGL((k_first_hit<true, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
+    }
     return (int)hipGetLastError();
 }
 
@@ -636,8 +658,14 @@ int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *o
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    if (sc.large_scene) hipLaunchKernelGGL(k_occlude<true>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
-    else hipLaunchKernelGGL(k_occlude<false>, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, (unsigned long long)n, out);
+    const dim3 grid((uint32_t)blocks), block(kTraceBlock);
+    const unsigned long long count = n;
+    switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((k_occlude<false, false>), grid, block, 0, stream, sc, rays, count, out); break;
+        case 1: hipLaunchKernelGGL((k_occlude<false, true>), grid, block, 0, stream, sc, rays, count, out); break;
+        case 2: hipLaunchKernelGGL((k_occlude<true, false>), grid, block, 0, stream, sc, rays, count, out); break;
+        default: hipLaunchKernelGGL((k_occlude<true, true>), grid, block, 0, stream, sc, rays, count, out); break;
+    }
     return (int)hipGetLastError();
 }
 

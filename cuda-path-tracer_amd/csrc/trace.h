@@ -42,10 +42,12 @@ __device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return mak
 // LDS_ENTRIES * kTraceBlock entries and a local array of kSpillEntries); this holds their addresses.
 // LEAF_WEIGHT rides along because it is, like the stack's shape, a choice each kernel build makes for the
 // scenes it is meant for (see Traversal::vote_step).
-template <int LDS_ENTRIES, int LEAF_WEIGHT = 1>
+// FAST selects the ordered traversal (see Traversal) and rides along for the same reason.
+template <int LDS_ENTRIES, int LEAF_WEIGHT = 1, bool FAST = false>
 struct TraceStackT {
     static constexpr int kLdsEntries = LDS_ENTRIES;
     static constexpr int kLeafWeight = LEAF_WEIGHT;
+    static constexpr bool kFast = FAST;
     LdsStack lds;
     PrivateStack spill;
     Counters *counters;       // where an entry that does not fit is reported (may be null)
@@ -107,6 +109,17 @@ struct RayFrame {
         fast = boxes_ok && moderate(dir.x) && moderate(dir.y) && moderate(dir.z) && coords_in_fast_range(origin.x, origin.y, origin.z);
         r = fast ? v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z) : v3(0.0f);
     }
+    // the ordered traversal multiplies by the reciprocal whatever the magnitudes (a zero component gives an infinity,
+    // which orders the slab of that axis like the quotient by zero does)
+    __device__ inline void set_recip(V3 origin, V3 dir) {
+        o = origin;
+        d = dir;
+        fast = true;
+        r = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    }
+    template <bool FAST> __device__ inline void set_for(V3 origin, V3 dir, bool boxes_ok) {
+        if constexpr (FAST) set_recip(origin, dir); else set(origin, dir, boxes_ok);
+    }
 };
 
 // accel.cuh:33-52 without the tmax clause; returns the entry distance in t0
@@ -131,6 +144,34 @@ __device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, 
         t1 = fminf(xb, fminf(yb, zb));
     }
     return t0 <= t1 && t1 > tmin;
+}
+
+// The slab test of the ordered ("fast") traversal: distances by multiplication with the reciprocal direction (two
+// operations per plane instead of a correctly rounded quotient), the exit distance widened by four units in the
+// last place so that the rounding of the products never rejects a box the exact quotients admit.  It departs from
+// accel.cuh:33-52 only in that rounding: a box may be entered that the reference skips, never the other way round
+// (up to entry distances that tie with the current hit distance, which the callers admit on equality).
+__device__ inline bool slab_fast(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayFrame &f, float tmin, float &t0) {
+    const float x0 = (bminx - f.o.x) * f.r.x, x1 = (bmaxx - f.o.x) * f.r.x;
+    const float y0 = (bminy - f.o.y) * f.r.y, y1 = (bmaxy - f.o.y) * f.r.y;
+    const float z0 = (bminz - f.o.z) * f.r.z, z1 = (bmaxz - f.o.z) * f.r.z;
+    t0 = fmaxf(fminf(x0, x1), fmaxf(fminf(y0, y1), fminf(z0, z1)));
+    const float t1 = fminf(fmaxf(x0, x1), fminf(fmaxf(y0, y1), fmaxf(z0, z1))) * 1.0000005f;
+    return t0 <= t1 && t1 > tmin;
+}
+template <bool FAST>
+__device__ inline bool slab_of(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayFrame &f, float tmin, float &t0) {
+    if constexpr (FAST) return slab_fast(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, f, tmin, t0);
+    else return slab(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, f, tmin, t0);
+}
+// Is a box whose entry distance is t0 still of interest with the current reach?  The reference's test is strict
+// (accel.cuh:51).  The ordered traversal of closest hits admits equality: a triangle at exactly the current hit
+// distance may still win the tie (see Traversal), and it may sit in a box that begins at that distance.
+// Its entry distances carry the rounding of slab_fast (up to 1.5 ulp too large), so its reach is widened like the exit
+// distance: a box is never skipped whose exact entry distance lies within the reach.
+template <bool FAST> __device__ inline bool within_reach(float t0, float tmax, bool any) {
+    if constexpr (FAST) return any ? t0 < tmax * 1.0000005f : t0 <= tmax * 1.0000005f;
+    else return t0 < tmax;
 }
 
 // trimesh.cuh:14-43 on a pre-gathered record
@@ -160,6 +201,36 @@ __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, fl
     return false;
 }
 
+// The same test for the ordered traversal: a hit at exactly the current reach is reported too (`tie`), the caller
+// decides whether it replaces the one it holds.
+__device__ inline bool tri_test_or_tie(const TriRecord *rec, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim, bool &tie) {
+    GlobalF4 q = (GlobalF4)rec;
+    float4 a = load_f4(q, 0), b = load_f4(q, 1), c = load_f4(q, 2);
+    V3 p0 = v3(a.x, a.y, a.z), e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
+    V3 qv = cross(d, e2);
+    float det = dot(e1, qv);
+    tie = false;
+    if (det != 0.0f) {
+        det = 1.0f / det;
+        V3 s = o - p0;
+        float v = dot(s, qv) * det;
+        if (v >= 0.0f) {
+            V3 r = cross(s, e1);
+            float w = dot(d, r) * det;
+            float u = 1.0f - v - w;
+            if (w >= 0.0f && u >= 0.0f) {
+                float tt = dot(e2, r) * det;
+                if (tt > tmin && tt <= tmax) {
+                    t = tt; bv = v; bw = w; prim = __float_as_uint(a.w);
+                    tie = tt == tmax;
+                    return true;
+                }
+            }
+        }
+    }
+    return false;
+}
+
 constexpr uint32_t kNoNode = 0xffffffffu;
 
 // The wave runs the kind of step that has the most lanes, with lanes at a triangle or at an instance counted
@@ -180,9 +251,22 @@ constexpr int kLeafWeightLargeScene = 4;
 // and wait.  A lane's own sequence of box tests, triangle tests and stack operations is exactly
 // the sequential one, so results do not depend on the vote, but the expensive node step always
 // runs with as many lanes as possible instead of being serialised with the other two every trip.
+//
+// Two traversal orders, chosen by the stack type a kernel is built with (Stack::kFast):
+//  * exact (default): the reference's order and arithmetic, as described at the top of this file; results are the
+//    reference's bit for bit.
+//  * ordered ("fast"): of two children that are hit, the one the ray enters first is walked first and the other
+//    waits with its entry distance, so a hit found early culls most of what is behind it (the reference walks the
+//    right child first whatever the ray, accel.cuh:84-85, about twice the node visits on surfaces and several times
+//    on scattered triangles); slab distances by reciprocal multiplication (slab_fast).  The triangle test is the
+//    same, so a hit's distance and barycentrics are the same numbers.  What can differ is WHICH of several triangles
+//    at the same or nearly the same distance is reported: the reference reports the first one its order meets whose
+//    box it entered; the ordered traversal reports the nearest, and among hits at exactly equal distance the one
+//    later in (top-level leaf position, sorted-leaf slot) order, which is the one the reference meets first and keeps.
 struct Traversal {
     uint32_t cur = kNoNode;
     uint32_t sp = 0, sp_base = 0, inst_id = 0;
+    uint32_t inst_pos = 0, hit_pos = 0, hit_slot = 0;   // ordered traversal: top-level leaf position of the instance being walked; of the hit held; its sorted-leaf slot
     bool in_blas = false, found = false;
     float tmin = 0.0f, tmax = 0.0f;
     RayFrame world, f;
@@ -191,6 +275,7 @@ struct Traversal {
     Hit hit;
 
     // tests the top-level root box; afterwards live() tells whether there is anything to walk
+    template <bool FAST = false>
     __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float tmin_, float tmax_, LaneCounters &cnt) {
         cnt.rays++;
         cur = kNoNode;
@@ -199,16 +284,17 @@ struct Traversal {
         tmin = tmin_; tmax = tmax_;
         nodes = sc.top_nodes;
         const AccelRoot troot = *sc.top_root;
-        world.set(ow, dw, troot.flags == 0);
+        world.set_for<FAST>(ow, dw, troot.flags == 0);
         f = world;
         float t0;
-        if (slab(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], world, tmin, t0) && t0 < tmax) cur = troot.ref;
+        if (slab_of<FAST>(troot.bmin[0], troot.bmin[1], troot.bmin[2], troot.bmax[0], troot.bmax[1], troot.bmax[2], world, tmin, t0) && t0 < tmax) cur = troot.ref;
     }
     __device__ inline bool live() const { return cur != kNoNode; }
 
     // returns false when no lane of the wave that called it has work left
     template <bool ANY, class Stack>
     __device__ inline bool vote_step(const SceneDev &sc, Stack &st, LaneCounters &cnt) {
+        constexpr bool FAST = Stack::kFast;
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -223,11 +309,21 @@ struct Traversal {
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
                 cnt.nodes++;
                 float t0l, t0r;
-                bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l);
-                bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r);
-                if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
-                if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
-                else need_pop = true;
+                if constexpr (FAST) {
+                    const bool hl = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l) && within_reach<true>(t0l, tmax, ANY);
+                    const bool hr = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r) && within_reach<true>(t0r, tmax, ANY);
+                    const uint32_t lc = __float_as_uint(q3.x), rc = __float_as_uint(q3.y);
+                    const bool left_first = t0l < t0r;              // equal entry distances: the right child, as the reference
+                    if (hl && hr) { st.push(sp, left_first ? rc : lc, left_first ? t0r : t0l); sp++; }
+                    if (hl || hr) cur = (hl && (left_first || !hr)) ? lc : rc;
+                    else need_pop = true;
+                } else {
+                    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l);
+                    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r);
+                    if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                    if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                    else need_pop = true;
+                }
             }
         } else if (ct >= ci) {
             if (is_tri) {
@@ -235,7 +331,21 @@ struct Traversal {
                 uint32_t prim;
                 cnt.tris++;
                 need_pop = true;
-                if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, tmin, tmax, t, bv, bw, prim)) {
+                if constexpr (FAST && !ANY) {
+                    bool tie;
+                    const uint32_t slot = cur & ~kLeafBit;
+                    if (tri_test_or_tie(tris + slot, f.o, f.d, tmin, tmax, t, bv, bw, prim, tie)) {
+                        // at equal distance the hit later in (top-level leaf, sorted-leaf) order stays: the one the
+                        // reference, which walks leaves in descending order, meets first and keeps
+                        const bool later = inst_pos > hit_pos || (inst_pos == hit_pos && slot > hit_slot);
+                        if (!tie || !found || later) {
+                            found = true;
+                            tmax = t;
+                            hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                            hit_pos = inst_pos; hit_slot = slot;
+                        }
+                    }
+                } else if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, tmin, tmax, t, bv, bw, prim)) {
                     found = true;
                     if (ANY) {
                         need_pop = false;
@@ -255,11 +365,12 @@ struct Traversal {
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
-                f.set(xyz(mul(inv, v4(world.o, 1.0f))), xyz(mul(inv, v4(world.d, 0.0f))), r.flags == 0);
+                if constexpr (FAST) inst_pos = in.tlas_position;
+                f.set_for<FAST>(xyz(mul(inv, v4(world.o, 1.0f))), xyz(mul(inv, v4(world.d, 0.0f))), r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
-                if (slab(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, tmin, t0) && t0 < tmax) cur = r.ref;
+                if (slab_of<FAST>(r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2], f, tmin, t0) && within_reach<FAST>(t0, tmax, ANY)) cur = r.ref;
                 else need_pop = true;
             }
         }
@@ -270,7 +381,7 @@ struct Traversal {
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);
-                if (__uint_as_float(e.y) < tmax) { cur = e.x; break; }
+                if (within_reach<FAST>(__uint_as_float(e.y), tmax, ANY)) { cur = e.x; break; }
             }
         }
         return true;
@@ -283,7 +394,7 @@ struct Traversal {
 template <bool ANY, class Stack>
 __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, Stack &st, LaneCounters &cnt) {
     Traversal t;
-    if (active) t.begin(sc, ow, dw, tmin, tmax, cnt);
+    if (active) t.begin<Stack::kFast>(sc, ow, dw, tmin, tmax, cnt);
     while (t.vote_step<ANY>(sc, st, cnt)) {}
     if (!ANY && t.found) { hit = t.hit; tmax = t.tmax; }
     return t.found;

@@ -148,6 +148,16 @@ int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour,
  * extension ray is finished walk them instead of idling; 3 = 5 or 4 by scene size (4 from 65,536
  * triangles on; each is the fastest of all on MI355X on its side).  Same image in all of them. */
 int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
+/* Traversal: 0 = exact (default): the visit order and arithmetic of AccelTop/AccelBottom::Intersect and BboxIntersect
+ * (src/kernels/accel/accel.cuh:33-52, 68-90, 124-150: right child first, six correctly rounded quotients per box), so
+ * first-hit ids, distances and images are the reference's bit for bit.  1 = fast: of two children that are hit the
+ * nearer one is walked first and the other waits with its entry distance; slab distances by multiplication with the
+ * reciprocal direction, the exit distance widened by 4 ulp.  It departs from accel.cuh:33-52 (rounding of the slab
+ * distances) and accel.cuh:84-85 (visit order); the triangle test is unchanged, so a reported hit has the same
+ * distance and barycentrics.  What may differ is which of several triangles at the same or nearly the same distance is
+ * reported (the nearest; at exactly equal distance the one later in instance and sorted-leaf order).  Applies to
+ * cpt_tracer_first_hit / cpt_tracer_occlude and to integrators 3, 4 and 5; integrators 0, 1 and 2 always run exact. */
+int cpt_tracer_set_traversal(cpt_tracer *t, int mode);
 /* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
  * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette
  * paths costs a kernel sequence per bounce otherwise).  Negative = never, queues to the end
@@ -242,6 +252,7 @@ cpt_multi *cpt_multi_create(cpt_scene *s, uint32_t film_width, uint32_t film_hei
 void cpt_multi_destroy(cpt_multi *m);
 int cpt_multi_set_max_depth(cpt_multi *m, int max_depth);
 int cpt_multi_set_integrator(cpt_multi *m, int mode);
+int cpt_multi_set_traversal(cpt_multi *m, int mode);                          /* as cpt_tracer_set_traversal, for every shard */
 int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples);
 int cpt_multi_build_buffers(cpt_multi *m);
 int cpt_multi_render(cpt_multi *m, uint32_t total_spp, float *elapsed_ms);
