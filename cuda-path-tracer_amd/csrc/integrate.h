@@ -81,32 +81,54 @@ __device__ inline void film_accumulate(const RenderParams &p, uint32_t pixel_ind
 // only when the pixel has received k of them, so the pixel's samples are accumulated in sample order whatever
 // order their paths end in, and the film holds bit for bit what one launch per sample leaves.  Returns false when
 // it is not this path's turn yet (the caller tries again later; it must not spin, the earlier path may be a lane
-// of the same wave).  The film words and the turn word are device-scope atomics: a pixel's paths may run on
-// different XCDs, whose L2s do not see each other's plain stores.  They are relaxed ones, ordered by hand: an
-// acquire or release at this scope invalidates or writes back whole caches, and the traversal lives on its L1.
-// The film loads are issued after the turn word has arrived (the branch needs it), and the turn store after the
-// film stores have been acknowledged (the wait below).
+// of the same wave).
+//
+// A pixel's paths may run on different XCDs, whose L2s do not see each other's plain stores, so the pixel and its
+// turn word are accessed at device scope.  Default build: the pixel moves as ONE 16-byte device-scope load and ONE
+// 16-byte write-through store (a quarter of the memory transactions of four dword accesses; 1 % faster on the Cornell
+// box), the turn word as
+// relaxed device-scope atomics, and the order between them is kept by hand: the pixel load is issued after the turn
+// word has arrived (the branch needs it), and the turn store after the pixel store has been acknowledged (the wait
+// behind it).  An acquire or release at this scope would invalidate or write back whole caches, and the traversal
+// lives on its L1.  That hand ordering is outside the language's memory model; a build with
+// -DCPT_FILM_ORDER_BY_FENCES uses an acquire load and a release store of the turn word instead (slower, same film),
+// so a toolchain or target change that breaks the hand-ordered form can be told apart by comparing the two.
+typedef float FilmF4 __attribute__((ext_vector_type(4)));
+
 __device__ inline bool film_accumulate_in_order(const RenderParams &p, uint32_t pixel_index, uint32_t pass, V3 color) {
     uint32_t *turn = p.order + pixel_index;
+    FilmF4 *pixel = reinterpret_cast<FilmF4 *>(p.output) + pixel_index;
+#ifdef CPT_FILM_ORDER_BY_FENCES
+    if (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != pass) return false;
+    FilmF4 prev = *pixel;
+#else
     if (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pass) return false;
-    asm volatile("" ::: "memory");
+    FilmF4 prev;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(prev)
+                 : "v"(pixel)
+                 : "memory");
+#endif
     if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
-    float *out = p.output + 4 * (size_t)pixel_index;
-    const float px = __hip_atomic_load(out + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), py = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                pz = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), pw = __hip_atomic_load(out + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float4 res;
+    FilmF4 res;
     if (p.sum_mode) {
-        res = make_float4(px + color.x, py + color.y, pz + color.z, pw + 1.0f);
+        res = FilmF4{prev.x + color.x, prev.y + color.y, prev.z + color.z, prev.w + 1.0f};
     } else {
         float a = 1.0f / (float)(p.spp + pass);
-        res = make_float4(px * (1.0f - a) + color.x * a, py * (1.0f - a) + color.y * a, pz * (1.0f - a) + color.z * a, pw * (1.0f - a) + 1.0f * a);
+        res = FilmF4{prev.x * (1.0f - a) + color.x * a, prev.y * (1.0f - a) + color.y * a, prev.z * (1.0f - a) + color.z * a, prev.w * (1.0f - a) + 1.0f * a};
     }
-    __hip_atomic_store(out + 0, res.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 1, res.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 2, res.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 3, res.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CPT_FILM_ORDER_BY_FENCES
+    *pixel = res;
+    __hip_atomic_store(turn, pass + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 :
+                 : "v"(pixel), "v"(res)
+                 : "memory");
     __hip_atomic_store(turn, pass + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     return true;
 }
 

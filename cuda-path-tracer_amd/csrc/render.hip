@@ -296,8 +296,12 @@ template <bool MAPS, bool DENSE, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
-    // the shadow ray of each lane's path: (origin, reach), (direction, fast-division flag), (1 / direction, -), (light contribution, reached the light)
+    // the shadow ray of each lane's path, four 16-byte fields next to each other (64 bytes per lane): (origin, reach),
+    // (direction, fast-division flag), (1 / direction, -), (light contribution, reached the light).  Field-major storage
+    // ([field][lane], no bank conflicts between the lanes of a wave) was measured too and is 3.5 % slower on the Cornell
+    // box (1219 against 1263 Mpaths/s): a lane reads its three fields with one address and immediate offsets here.
     __shared__ float4 s_pool[4 * kTraceBlock];
+    auto pool = [&](uint32_t field, uint32_t slot) -> float4 & { return s_pool[4 * slot + field]; };
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
     TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
@@ -352,25 +356,24 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         uint32_t pool_next = 0;
 
         // ---- walk; lanes without a ray take shadow rays from the list
-        float *const pool_words = reinterpret_cast<float *>(s_pool);
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = !own;
             const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) {
                 if (own) { ow = s.l.ro; dw = s.l.rd; }
-                else { float4 a = s_pool[4 * (wave_base + job)], b = s_pool[4 * (wave_base + job) + 1]; ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
+                else { float4 a = pool(0, wave_base + job), b = pool(1, wave_base + job); ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
             }, shadow);
             if (moved && (trip & kPoolPeriodMask) != kPoolPeriodMask) continue;
             const bool free_lane = !t.walking();
             if (free_lane && own) { ext_found = t.found; ext_hit = t.hit; own = false; }
             if (free_lane && job != 0xffffffffu) {
-                if (!t.found) pool_words[16 * (wave_base + job) + 15] = 1.0f;      // reached the light
+                if (!t.found) pool(3, wave_base + job).w = 1.0f;      // reached the light
                 job = 0xffffffffu;
             }
             const unsigned long long free_mask = __ballot(free_lane);
             const uint32_t avail = pool_count - pool_next, rank = __popcll(free_mask & lt_mask);
             if (free_lane && rank < avail) {
                 job = s_order[wave_base + pool_next + rank];
-                const float4 a = s_pool[4 * (wave_base + job)], b = s_pool[4 * (wave_base + job) + 1], c = s_pool[4 * (wave_base + job) + 2];
+                const float4 a = pool(0, wave_base + job), b = pool(1, wave_base + job), c = pool(2, wave_base + job);
                 Flow::Prepared q;
                 q.r = v3(c.x, c.y, c.z);
                 q.fast = __float_as_uint(b.w) != 0u;
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         // the scene's box has nothing between the point and the light.
         if (s.l.alive) {
             if (s.has_shadow) {
-                const float4 c = s_pool[4 * threadIdx.x + 3];
+                const float4 c = pool(3, threadIdx.x);
                 if (c.w != 0.0f) s.l.color = s.l.color + v3(c.x, c.y, c.z);
                 s.has_shadow = false;
             }
@@ -397,10 +400,10 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
                 const Flow::Prepared q = Flow::prepare<FAST>(sc, pos, dir, reach);
                 cnt.rays++;
                 if (!q.enters) { s.l.color = s.l.color + contribution; return false; }
-                s_pool[4 * threadIdx.x] = make_float4(pos.x, pos.y, pos.z, reach);
-                s_pool[4 * threadIdx.x + 1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(q.fast ? 1u : 0u));
-                s_pool[4 * threadIdx.x + 2] = make_float4(q.r.x, q.r.y, q.r.z, 0.0f);
-                s_pool[4 * threadIdx.x + 3] = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                pool(0, threadIdx.x) = make_float4(pos.x, pos.y, pos.z, reach);
+                pool(1, threadIdx.x) = make_float4(dir.x, dir.y, dir.z, __uint_as_float(q.fast ? 1u : 0u));
+                pool(2, threadIdx.x) = make_float4(q.r.x, q.r.y, q.r.z, 0.0f);
+                pool(3, threadIdx.x) = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
                 return true;
             });
         }
