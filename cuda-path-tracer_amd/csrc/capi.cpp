@@ -409,7 +409,7 @@ int cpt_tracer_update(cpt_tracer *t) {
 }
 int cpt_tracer_reset_accumulation(cpt_tracer *t) {
     TRACER_OR_FAIL(t);
-    return Guard([&] { t->tracer->ResetAccumelation(); t->film->Clear(t->tracer->Stream()); return CPT_OK; });
+    return Guard([&] { t->tracer->ResetAccumelation(); t->film->Clear(t->tracer->Stream()); t->tracer->NoteFilmCleared(); return CPT_OK; });
 }
 int cpt_tracer_synchronize(cpt_tracer *t) {
     TRACER_OR_FAIL(t);
@@ -427,6 +427,7 @@ int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_co
 
 float *cpt_tracer_film_device_ptr(cpt_tracer *t) {
     if (!t) return nullptr;
+    t->tracer->NoteFilmExposed();
     try { return t->film->DeviceMap(t->tracer->Stream()); } catch (const std::exception &e) { Fail(CPT_ERR_DEVICE, e.what()); return nullptr; }
 }
 int cpt_tracer_film_read(cpt_tracer *t, float *rgba) {

@@ -136,6 +136,9 @@ struct RenderParams {
     // pixel has received, which is what keeps a pixel's samples arriving in sample order.
     uint32_t spp_count = 1;
     uint32_t *order = nullptr;
+    // Running-mean launches of several samples into a film whose alpha is 0 or 1 everywhere (a film only ever written by
+    // running-mean samples and clears) need no `order` array: the count travels in the pixel's alpha, see film_accumulate_in_order.
+    int turn_in_alpha = 0;
 };
 
 }  // namespace cpt

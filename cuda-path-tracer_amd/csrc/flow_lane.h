@@ -233,7 +233,7 @@ __device__ inline void flow_shade(const SceneDev &sc, const RenderParams &p, Flo
         s.has_shadow = false;
         s.has_ext = false;
         s.ext_traced = false;
-        if (p.order) {
+        if (p.order || p.turn_in_alpha) {
             l.film_pending = !film_accumulate_in_order(p, l.pixel_index, l.pass, l.color);
             l.alive = l.film_pending;
         } else {

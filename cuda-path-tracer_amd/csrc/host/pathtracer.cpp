@@ -92,6 +92,7 @@ bool PathTracer::RefreshEdits() {
     if (changed) {
         ResetAccumelation();
         film_.Clear(stream_);
+        film_alpha_unit_ = true;
     }
     return changed;
 }
@@ -308,6 +309,7 @@ void PathTracer::Update() {
     RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
+        if (last_width_ != 0) film_alpha_unit_ = true;       // a resized film starts from zeros
         last_width_ = film_.Width();
         last_height_ = film_.Height();
     }
@@ -331,6 +333,7 @@ void PathTracer::UpdateMany(uint32_t count) {
     RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
+        if (last_width_ != 0) film_alpha_unit_ = true;       // a resized film starts from zeros
         last_width_ = film_.Width();
         last_height_ = film_.Height();
     }
@@ -357,7 +360,11 @@ void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
             const unsigned long long fits = tiles ? 0xffffffffull / (tiles * cpt::kSegmentSlots) : 1;       // slot numbers are 32 bits
             batch = (uint32_t)std::min<unsigned long long>({(unsigned long long)count, (unsigned long long)samples_per_launch_, fits ? fits : 1});
         }
-        if (batch > 1) {
+        p.turn_in_alpha = 0;
+        if (batch > 1 && !p.sum_mode && film_alpha_unit_ && p.output == film_.DeviceMap(stream_)) {
+            p.turn_in_alpha = 1;           // the pixel's alpha carries the count during the launch
+            p.order = nullptr;
+        } else if (batch > 1) {
             const size_t words = (size_t)p.width * p.height;
             if (order_.Size() != words * sizeof(uint32_t)) order_.Allocate(words * sizeof(uint32_t));
             order_.Zero(stream_);
@@ -451,6 +458,7 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
     RefreshEdits();
+    if (!output && sum_mode) film_alpha_unit_ = false;        // the film's alpha becomes a sample count
     cpt::RenderParams p;
     p.output = output ? output : film_.DeviceMap(stream_);
     p.width = output ? width : film_.Width();

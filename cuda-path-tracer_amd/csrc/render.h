@@ -20,7 +20,8 @@ constexpr uint32_t kRegenQueueWords = 2 * kCursorSetWords;
 // variant: 0 = k_render_regen; 1 = the build that keeps traversal state across shading and re-enters the loop with partly
 // finished waves (k_render_flow); 2 = the build whose finished lanes walk the wave's pooled shadow rays (k_render_pool).
 // sc.fast_traversal selects the builds of variants 1 and 2 with the ordered traversal (variant 0 has none and runs exact).
-// p.spp_count > 1 (variants 1 and 2 only): one launch renders that many consecutive samples; p.order must point to
+// p.spp_count > 1 (variants 1 and 2 only): one launch renders that many consecutive samples; p.turn_in_alpha is set (running
+// mean into a film whose alpha is 0 or 1 everywhere) or p.order must point to
 // width * height zeroed words.  The film ends up bit for bit as after one launch per sample.
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream);
 int render_regen_resident_blocks(int device, bool dense, int variant, bool fast);

@@ -1,6 +1,6 @@
 """Synthetic-scene numbers (the 1M / 10M triangle configurations): LBVH build through the tracer, primary-ray
 first-hit rate and path-tracing rate.  usage: python scripts/bench_synth.py <kind> <ntris> [width height spp depth integrators]
-integrators: comma list of mode[:wavefront tail], e.g. 0,1,2:-1,2:3"""
+integrators: comma list of mode[:wavefront tail], e.g. 0,1,2:-1,2:3; traversal 0 exact (default) or 1 fast; samples per launch (default 32)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,6 +15,8 @@ H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 spp = int(sys.argv[5]) if len(sys.argv) > 5 else 8
 depth = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 modes = sys.argv[7] if len(sys.argv) > 7 else "0"
+traversal = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+per_launch = int(sys.argv[9]) if len(sys.argv) > 9 else 32
 t0 = time.time()
 objs, cam = synthetic_scene(kind, ntris)
 # a camera low over the terrain (inside the cube of the soup) so that nearly every 16:9 ray hits
@@ -27,6 +29,8 @@ for o in objs:
 sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
 t1 = time.time()
 tr = cpt.Tracer(sc, W, H, max_depth=depth)
+tr.set_traversal(traversal)
+tr.set_samples_per_launch(per_launch)
 tr.build_buffers(profile=True)
 t2 = time.time()
 print(f"{kind} {len(objs[0]['indices'])//3} tris: generate {t1-t0:.1f}s, build_buffers {t2-t1:.2f}s, stages {tr.build_stage_ms()}", flush=True)
