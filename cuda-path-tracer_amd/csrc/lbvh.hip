@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(kBlock) k_morton_tile(uint64_t *__restrict__ k
     }
 }
 
+constexpr int kHistWide = 4;                // the large configuration's histogram kernel: 4 x 256 threads, a quarter of the keys per lane
 constexpr int kPasses = 4;                  // 8-bit digits of key bits 32..63 (the 30 code bits)
 constexpr uint32_t kMortonBlocks = 1024;    // persistent workgroups of the key kernel
 
@@ -170,6 +171,7 @@ constexpr uint32_t kSortBlocks = 1024;            // persistent workgroups of a 
 constexpr uint32_t kTileCount = 0x40000000u;      // the word is this tile's own digit count
 constexpr uint32_t kTilePrefix = 0x80000000u;     // the word is the count of this and all earlier tiles
 constexpr uint32_t kTileValue = 0x3fffffffu;
+constexpr int kLookBackWindow = 4;                // predecessor tiles examined per round trip (1, 4, 8, 16 measured: 0.450, 0.429, 0.437, 0.455 ms for the 10M sort)
 constexpr uint32_t kLookBackSpins = 1u << 21;     // far beyond any wait seen: a lost predecessor becomes a reported error, not a hang
 
 __global__ void __launch_bounds__(kBlock) k_onesweep(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t n, int shift,
@@ -237,17 +239,31 @@ __global__ void __launch_bounds__(kBlock) k_onesweep(const uint64_t *__restrict_
     uint32_t before_tiles = 0;
     bool lost = false;
     if (tile != 0) {
-        uint32_t back = tile;
+        // A look-back step is a device-scope load, a round trip past this XCD's L2 of a microsecond or more.  The words of
+        // kLookBackWindow predecessors are therefore asked for together and consumed nearest first, up to the first one that
+        // is a prefix (done) or not yet published (asked for again, with the ones behind it).
+        int next = (int)tile - 1;
+        uint32_t spins = 0;
         for (;;) {
-            --back;
-            const uint32_t *theirs = tile_status + (size_t)back * kBins + t;
-            uint32_t word = 0, spins = 0;
-            do {
-                word = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while (word == 0 && ++spins <= kLookBackSpins);
-            if (word == 0) { lost = true; break; }
-            before_tiles += word & kTileValue;
-            if (word & kTilePrefix) break;
+            uint32_t word[kLookBackWindow];
+#pragma unroll
+            for (int k = 0; k < kLookBackWindow; k++) {
+                const int idx = next - k;
+                word[k] = idx >= 0 ? __hip_atomic_load(tile_status + (size_t)idx * kBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kTilePrefix;
+            }
+            int used = 0;
+            bool done = false;
+#pragma unroll
+            for (int k = 0; k < kLookBackWindow; k++) {
+                if (!done && used == k && word[k] != 0u) {
+                    before_tiles += word[k] & kTileValue;
+                    used = k + 1;
+                    done = (word[k] & kTilePrefix) != 0u;
+                }
+            }
+            if (done) break;
+            next -= used;
+            if (used == 0 && ++spins > kLookBackSpins) { lost = true; break; }
         }
         // published even after a give-up, so that no successor waits for this tile in turn
         __hip_atomic_store(mine, kTilePrefix | ((before_tiles + total_d) & kTileValue), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -289,23 +305,23 @@ __global__ void __launch_bounds__(kBlock) k_onesweep(const uint64_t *__restrict_
 // for another one; on this part that is faster than the look-back of the one-kernel pass above,
 // whose every step is a round trip past the per-XCD L2s (10M keys: 0.35 ms against 0.36-0.49 ms).
 // ------------------------------------------------------------------------------------------
-template <int ITEMS>
-__global__ void __launch_bounds__(kBlock) k_hist(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t *__restrict__ tile_hist,
+template <int ITEMS, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_hist(const uint64_t *__restrict__ keys, uint32_t n, int shift, uint32_t *__restrict__ tile_hist,
                                                   uint32_t num_tiles) {
     __shared__ uint32_t hist[kBins];
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < kBins) hist[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t base = blockIdx.x * (kBlock * ITEMS);
+    uint32_t base = blockIdx.x * (THREADS * ITEMS);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        uint32_t i = base + k * kBlock + threadIdx.x;
+        uint32_t i = base + k * THREADS + threadIdx.x;
         if (i < n) {
-            uint32_t d = (uint32_t)(keys[i] >> shift) & (kBins - 1);
+            uint32_t d = (uint32_t)(keys[i] >> shift) & (kBins - 1);       // plain load: the scatter kernel reads the same keys again, out of the caches (non-temporal: 0.37 instead of 0.31 ms)
             atomicAdd(&hist[d], 1u);
         }
     }
     __syncthreads();
-    tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];   // bin-major
+    if (threadIdx.x < kBins) tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];   // bin-major
 }
 
 // one workgroup per bin: exclusive scan of that bin's counts over all tiles, total to bin_total
@@ -325,7 +341,13 @@ __global__ void __launch_bounds__(kBlock) k_scan_bins(uint32_t *__restrict__ til
     if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-template <int ITEMS>
+__device__ inline uint32_t xcd_band(uint32_t b, uint32_t nb) {
+    const uint32_t q = nb / 8, r = nb % 8, xcd = b % 8, k = b / 8;
+    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+template <int ITEMS, bool BANDS>
 __global__ void __launch_bounds__(kBlock, 4) k_scatter(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t n, int shift,
                                                      const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ bin_total,
                                                      uint32_t num_tiles) {
@@ -336,11 +358,16 @@ __global__ void __launch_bounds__(kBlock, 4) k_scatter(const uint64_t *__restric
     __shared__ uint32_t tmp[kWaves + 1];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t tile_base = blockIdx.x * (kBlock * ITEMS);
+    // Workgroups are dealt to the 8 XCDs round robin.  A tile's run of a digit is followed in memory by the next tile's run
+    // of that digit, and the two share a cache line; with one contiguous band of tiles per XCD (BANDS) both halves of that
+    // line are written through the same L2, which can then write it out whole: 10M keys sort in 0.301 instead of 0.321 ms.
+    // Small inputs, whose keys stay in the caches anyway, lose by it (1M: 0.080 against 0.074 ms) and keep the plain order.
+    const uint32_t tile = BANDS ? xcd_band(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t tile_base = tile * (kBlock * ITEMS);
     const uint32_t tile_n = min((uint32_t)(kBlock * ITEMS), n - tile_base);
     // digit t's totals are not needed before the scatter: fetch them while the ranking runs
     const uint32_t bt = bin_total[t];
-    const uint32_t earlier_tiles = tile_hist[(size_t)t * num_tiles + blockIdx.x];
+    const uint32_t earlier_tiles = tile_hist[(size_t)t * num_tiles + tile];
 #pragma unroll
     for (int i = 0; i < kWaves; i++) cnt[i][t] = 0;
     __syncthreads();
@@ -399,6 +426,105 @@ __global__ void __launch_bounds__(kBlock, 4) k_scatter(const uint64_t *__restric
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         uint32_t i = k * kBlock + t;
+        if (i < tile_n) {
+            uint64_t kk = staged[i];
+            uint32_t d = (uint32_t)(kk >> shift) & (kBins - 1);
+            keys_out[gbase[d] + i] = kk;
+        }
+    }
+}
+
+// The same scatter for large inputs with WAVES waves per workgroup (a tile is still WAVES * 64 * ITEMS keys): a streaming
+// kernel on this part runs fastest with few elements per lane and many waves in flight (see k_stream_copy in render.hip),
+// so the 4096-key tile of the large configuration is walked by 8 waves of 8 keys per lane instead of 4 waves of 16: the 10M
+// sort takes 0.267 ms instead of 0.292 (16 waves of 4 keys: 0.281).  The histogram kernel of these passes runs 16 waves of
+// 4 keys for the same reason (0.306 -> 0.293 ms).
+constexpr int kWideWaves = 8;
+template <int ITEMS, int WAVES, bool BANDS>
+__global__ void __launch_bounds__(WAVES * 64) k_scatter_wide(const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out, uint32_t n, int shift,
+                                                             const uint32_t *__restrict__ tile_hist, const uint32_t *__restrict__ bin_total, uint32_t num_tiles) {
+    constexpr int THREADS = WAVES * 64, TILE = THREADS * ITEMS;
+    __shared__ uint64_t staged[TILE];            // keys in tile-sorted order
+    __shared__ uint32_t cnt[WAVES][kBins];       // per-wave digit counts, then exclusive over waves
+    __shared__ uint32_t tile_off[kBins];         // first staged slot of each digit
+    __shared__ uint32_t gbase[kBins];            // global destination of staged slot 0 of each digit
+    __shared__ uint32_t tmp[2][kWaves];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t tile = BANDS ? xcd_band(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t tile_base = tile * TILE;
+    const uint32_t tile_n = min((uint32_t)TILE, n - tile_base);
+    uint32_t bt = 0, earlier_tiles = 0;
+    if (t < kBins) {
+        bt = bin_total[t];
+        earlier_tiles = tile_hist[(size_t)t * num_tiles + tile];
+    }
+    for (int i = t; i < WAVES * kBins; i += THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    uint64_t key[ITEMS];
+    uint32_t rank[ITEMS];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        uint32_t li = w * (64 * ITEMS) + r * 64 + lane;
+        bool valid = li < tile_n;
+        uint64_t k = valid ? keys_in[tile_base + li] : ~0ull;
+        key[r] = k;
+        uint32_t d = (uint32_t)(k >> shift) & (kBins - 1);
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        uint32_t before = __popcll(same & lt_mask);
+        uint32_t old = cnt[w][d];
+        if (valid && before == 0) cnt[w][d] = old + __popcll(same);
+        rank[r] = old + before;
+    }
+    __syncthreads();
+
+    // digit t (the first 256 threads): exclusive scan over waves, tile total, then the two scans over digits, done by the
+    // first four waves with one value per thread
+    uint32_t total_d = 0, inc_tile = 0, inc_bins = 0;
+    if (t < kBins) {
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            uint32_t c = cnt[i][t];
+            cnt[i][t] = total_d;
+            total_d += c;
+        }
+        inc_tile = wave_incl_scan(total_d);
+        inc_bins = wave_incl_scan(bt);
+        if (lane == 63) { tmp[0][w] = inc_tile; tmp[1][w] = inc_bins; }
+    }
+    __syncthreads();
+    if (t < kBins) {
+        uint32_t base_tile = 0, base_bins = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; i++) {
+            if (i < w) { base_tile += tmp[0][i]; base_bins += tmp[1][i]; }
+        }
+        const uint32_t off = base_tile + inc_tile - total_d;
+        tile_off[t] = off;
+        gbase[t] = (base_bins + inc_bins - bt) + earlier_tiles - off;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        uint32_t li = w * (64 * ITEMS) + r * 64 + lane;
+        if (li < tile_n) {
+            uint32_t d = (uint32_t)(key[r] >> shift) & (kBins - 1);
+            staged[tile_off[d] + cnt[w][d] + rank[r]] = key[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        uint32_t i = k * THREADS + t;
         if (i < tile_n) {
             uint64_t kk = staged[i];
             uint32_t d = (uint32_t)(kk >> shift) & (kBins - 1);
@@ -936,11 +1062,11 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
             for (int pass = 0; pass < kPasses; pass++) {
                 int shift = 32 + pass * kRadixBits;
                 if (pass == 0 && small) {}       // the key kernel counted this pass's digits
-                else if (small) hipLaunchKernelGGL(k_hist<kSmallItems>, dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
-                else hipLaunchKernelGGL(k_hist<kItems>, dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
+                else if (small) hipLaunchKernelGGL((k_hist<kSmallItems, kBlock>), dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
+                else hipLaunchKernelGGL((k_hist<kItems / kHistWide, kBlock * kHistWide>), dim3(nt), dim3(kBlock * kHistWide), 0, stream, src, n, shift, tile_hist, nt);
                 hipLaunchKernelGGL(k_scan_bins, dim3(kBins), dim3(kBlock), 0, stream, tile_hist, nt, bin_total);
-                if (small) hipLaunchKernelGGL(k_scatter<kSmallItems>, dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
-                else hipLaunchKernelGGL(k_scatter<kItems>, dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
+                if (small) hipLaunchKernelGGL((k_scatter<kSmallItems, false>), dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
+                                else hipLaunchKernelGGL((k_scatter_wide<kTile / (kWideWaves * 64), kWideWaves, true>), dim3(nt), dim3(kWideWaves * 64), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
                 uint64_t *t = src; src = dst; dst = t;
             }
         }

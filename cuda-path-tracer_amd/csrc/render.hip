@@ -511,11 +511,13 @@ __global__ void __launch_bounds__(256) k_div_selftest(uint32_t seed, uint32_t pe
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
-// Plain copy, 16 bytes per lane and trip, grid-stride: the rate the memory system gives a kernel that does
-// nothing but stream, to set next to the 8 TB/s nominal peak.
+// Plain copy: the rate the memory system gives a kernel that does nothing but stream, to set next to the 8 TB/s nominal
+// peak.  One 16-byte element per lane and one workgroup per 4 KB, no loop: measured against 2, 4 and 8 elements in flight
+// per lane and against persistent grids, this shape is the fastest on MI355X (6.2 TB/s read + written; 4 in flight 5.6,
+// 8 in flight 4.3, grid-stride loops 4.9-5.5), so a streaming kernel here wants many short workgroups, not long lanes.
 __global__ void __launch_bounds__(256) k_stream_copy(const RawF4 *__restrict__ src, RawF4 *__restrict__ dst, unsigned long long n16) {
-    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 // d_dst += d_src, one float4 (pixel) per lane and trip
@@ -552,8 +554,9 @@ int launch_film_finish(float *film, uint64_t pixels, hipStream_t stream) {
 int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t stream) {
     const unsigned long long n16 = bytes / 16;
     if (n16 == 0) return 0;
-    unsigned long long want = (n16 + 256 * 4 - 1) / (256 * 4);         // four trips per lane
-    const uint32_t blocks = (uint32_t)(want < 1u ? 1u : (want > 0x7fffffffull ? 0x7fffffffull : want));
+    const unsigned long long want = (n16 + 255) / 256;
+    if (want > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    const uint32_t blocks = (uint32_t)want;
     hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, stream, (const RawF4 *)src, (RawF4 *)dst, n16);
     return (int)hipGetLastError();
 }
