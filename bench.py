@@ -45,7 +45,7 @@ from conftest import load_cpt  # noqa: E402
 import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E, vendor peak
-VALU_PEAK_GINST = 256 * 4 * 2.4        # wave-instructions per ns the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4    # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz, four cycles each on a 16-lane SIMD
 COUNTER_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")
 KERNEL_OF = {0: "k_render_regen", 1: "k_render", 2: "k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow", 5: "k_render_pool"}
 INTEGRATOR_NAME = {0: "persistent megakernel (lane regeneration)", 1: "megakernel, one lane per pixel", 2: "wavefront (ray queues) + persistent tail",
@@ -72,6 +72,31 @@ def measured_counters(key):
         return json.load(open(COUNTER_FILE)).get(key)
     except Exception:
         return None
+
+
+def roofline_block(kernel, algorithmic_bytes, avg_ms, samples, m):
+    """Roofline object of one kernel launch.  Live: the launch duration (HIP events) and the algorithmic bytes (work
+    counters of this run).  From the counter passes kept under profiles/ (per sample, scaled to the samples this launch
+    held): HBM bytes and VALU instructions.  These traversal kernels read most of their algorithmic bytes from the caches, so
+    the binding unit is whichever of the two is busier: VALU issue (a wave64 instruction holds a 16-lane SIMD for four
+    cycles) or HBM; without counters only the nominal HBM figure can be given."""
+    alg_gbs = algorithmic_bytes / (avg_ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "avg_launch_ms": round(avg_ms, 5), "samples_per_launch": round(samples, 2), "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+         "algorithmic_gb_per_s": round(alg_gbs, 1), "algorithmic_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4)}
+    if not m:
+        r.update(bound="hbm", achieved=round(alg_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg_gbs / HBM_PEAK_GBS, 4), traffic=None,
+                 note="no counter pass for this launch shape: nominal figure, algorithmic bytes against the HBM peak")
+        return r
+    traffic = m["hbm_bytes_per_sample"] * samples
+    hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9
+    ginst = m["valu_insts_per_sample"] * samples / (avg_ms * 1e-3) / 1e9
+    if ginst / VALU_PEAK_GINST >= hbm_gbs / HBM_PEAK_GBS:
+        r.update(bound="valu", achieved=round(ginst, 1), peak=round(VALU_PEAK_GINST, 1), unit="G wave64 VALU instructions/s", frac=round(ginst / VALU_PEAK_GINST, 4))
+    else:
+        r.update(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_gbs / HBM_PEAK_GBS, 4))
+    r.update(traffic=int(traffic), hbm_gb_per_s=round(hbm_gbs, 1), hbm_frac=round(hbm_gbs / HBM_PEAK_GBS, 4), valu_frac=round(ginst / VALU_PEAK_GINST, 4),
+             counters={k: m[k] for k in ("valu_busy", "lanes_active", "l1_hit", "l2_hit", "salu_per_valu", "lds_bank_conflict_frac") if k in m})
+    return r
 
 
 def cpu_model():
@@ -188,15 +213,9 @@ def primary_ray_block(cpt, tracer, W, H, label):
         ms = tracer.timer_end() / reps
         c = tracer.counters()
         hits[tag] = (d_inst.to_host(), d_prim.to_host(), d_t.to_host())
-        gbs = traversal_bytes(c) / reps / (ms * 1e-3) / 1e9
         block = {"mrays_per_s": round(n / ms / 1e3, 1), "ms": round(ms, 4), "node_records_per_ray": round(c["node_visits"] / c["rays"], 2),
                  "triangles_per_ray": round(c["tri_tests"] / c["rays"], 2),
-                 "roofline": {"kernel": "k_first_hit", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}}
-        m = measured_counters(f"k_first_hit/{label}/{tag}")
-        if m:
-            block["roofline"]["traffic"] = int(m["hbm_bytes_per_launch"])
-            block["counters"] = {k: m[k] for k in ("valu_busy", "lanes_active", "l2_hit") if k in m}
+                 "roofline": roofline_block("k_first_hit", traversal_bytes(c) / reps, ms, 1, measured_counters(f"k_first_hit/{label}/{tag}"))}
         out[tag] = block
     e, f = hits["exact"], hits["fast"]
     out["fast_vs_exact"] = {"id_mismatches": int(((e[0] != f[0]) | (e[1] != f[1])).sum()), "fast_farther": int((f[2] > e[2]).sum()),
@@ -374,27 +393,9 @@ def main():
         avg_ms = kernel_ms / launches
         samples_in_launch = own / launches                               # what an average timed launch really held
         alg_bytes = bounce_bytes(counters, W * H * own) / launches
-        alg_gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
         m = measured_counters(f"{kernel_name}/{args.workload}/{args.traversal}") if (W, H) == (1024, 1024) or args.workload != "cornell-box-glass" else None
-        traffic = int(m["hbm_bytes_per_sample"] * samples_in_launch) if m else None
-        if args.workload == "cornell-box-glass":
-            # 36 triangles: the scene lives in the vector L1 (hit rate 98 %), the kernel is bound by VALU issue at partial lane
-            # use; the instruction count per sample comes from the counter passes, the launch duration from this run
-            roof = {"kernel": kernel_name, "bound": "valu", "unit": "G wave-instructions/s", "peak": round(VALU_PEAK_GINST, 1), "achieved": None, "frac": None,
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "samples_per_launch": round(samples_in_launch, 2), "launches": launches,
-                    "hbm_nominal": {"algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_gb_per_s": round(alg_gbs, 1), "frac_of_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
-                                    "note": "nominal: these bytes are served by the L1, not by HBM"}}
-            if m:
-                ginst = m["valu_insts_per_sample"] * samples_in_launch / (avg_ms * 1e-3) / 1e9
-                roof.update(achieved=round(ginst, 1), frac=round(ginst / VALU_PEAK_GINST, 4))
-                roof["counters"] = {k: m[k] for k in ("valu_busy", "lanes_active", "l1_hit", "l2_hit", "lds_bank_conflict_frac") if k in m}
-                roof["hbm_traffic_gb_per_s"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
-        else:
-            roof = {"kernel": kernel_name, "bound": "hbm", "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(alg_bytes),
-                    "samples_per_launch": round(samples_in_launch, 2), "launches": launches}
-            if m:
-                roof["counters"] = {k: m[k] for k in ("valu_busy", "lanes_active", "l1_hit", "l2_hit") if k in m}
+        roof = roofline_block(kernel_name, alg_bytes, avg_ms, samples_in_launch, m)
+        roof["launches"] = launches
         result["roofline"] = roof
     del tracer, scene
 
@@ -417,8 +418,12 @@ def main():
             sc, ntri = synthetic(cpt, "heightfield", 10_000_000, w, h)
             tr = cpt.Tracer(sc, w, h, max_depth=5)
             tr.set_samples_per_launch(32)
-            tr.build_buffers()
+            tr.build_buffers(profile=True)
+            stages = tr.build_stage_ms()
             block = {"scene": f"synthetic heightfield, {ntri} triangles (emissive quad included), {w}x{h}", "spp_total": S, "scaling": "strong",
+                     "bvh_ms": {"leaf_boxes": round(stages["leaf_boxes"], 4), "build": round(stages["to_traversable"] - stages["leaf_boxes"] - stages["pack_records"], 4),
+                                "pack_records": round(stages["pack_records"], 4), "to_traversable": round(stages["to_traversable"], 4),
+                                "note": "device time of one build inside build_buffers (first build of the process: scratch allocation excluded, caches cold)"},
                      "sharding": "replicas only" if world == 1 else f"{S} samples split over {world} ranks, one ncclReduce of the {w * h * 16 / 1e6:.1f} MB films"}
             if world == 1:
                 block["primary_rays"] = primary_ray_block(cpt, tr, w, h, "heightfield-10m")
@@ -444,16 +449,10 @@ def main():
                 if rank == 0:
                     v = {"mpaths_per_s": round(w * h * S / dt / 1e6, 1), "mrays_per_s": round(c["rays"] / dt / 1e6, 1), "ms_per_sample": round(dt / S * 1e3, 4),
                          "rays_per_path": round(c["rays"] / max(c["paths"], 1), 3), "node_records_per_ray": round(c["node_visits"] / max(c["rays"], 1), 2)}
-                    gbs = bounce_bytes(c_own, w * h * count) / (ms_dev * 1e-3) / 1e9            # rank 0's own launches against its own bytes
                     kname = KERNEL_OF[mode]
-                    v["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                     "traffic": None}
-                    m = measured_counters(f"{kname}/heightfield-10m/{'fast' if trav else 'exact'}") if depth == 5 else None
-                    if m:
-                        launches = max(1, -(-count // 32)) if mode == 4 else count
-                        v["roofline"]["traffic"] = int(m["hbm_bytes_per_sample"] * count / launches)
-                        v["roofline"]["samples_per_launch"] = round(count / launches, 2)
-                        v["counters"] = {k: m[k] for k in ("valu_busy", "lanes_active", "l1_hit", "l2_hit") if k in m}
+                    launches = max(1, -(-count // 32)) if mode == 4 else 1            # rank 0's own launches against its own bytes
+                    m = measured_counters(f"{kname}/heightfield-10m/{'fast' if trav else 'exact'}") if (depth == 5 and mode == 4) else None
+                    v["roofline"] = roofline_block(kname, bounce_bytes(c_own, w * h * count) / launches, ms_dev / launches, count / launches, m)
                     block[name] = v
             if rank == 0:
                 result["scene_10m"] = block

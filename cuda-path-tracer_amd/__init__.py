@@ -88,6 +88,13 @@ _sig("cpt_tracer_synchronize", C.c_int, [_vp])
 _sig("cpt_tracer_current_spp", C.c_uint32, [_vp])
 _sig("cpt_tracer_num_lights", C.c_uint32, [_vp])
 _sig("cpt_tracer_render_samples", C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_int, _vp, C.c_uint32, C.c_uint32])
+class RenderParams(C.Structure):
+    """cpt_render_params: the block kernel::PathTracer::Render takes (src/kernels/integrator/path.cuh:8-20)."""
+    _fields_ = [("scene", _vp), ("output", _vp), ("screen_width", C.c_uint32), ("screen_height", C.c_uint32), ("spp", C.c_uint32),
+                ("max_depth", C.c_uint32), ("channel", C.c_int)]
+
+
+_sig("cpt_path_tracer_render", C.c_int, [C.POINTER(RenderParams)])
 _sig("cpt_tracer_film_device_ptr", _vp, [_vp])
 _sig("cpt_tracer_film_read", C.c_int, [_vp, _f32])
 _sig("cpt_tracer_film_save", C.c_int, [_vp, C.c_char_p])
@@ -99,6 +106,7 @@ _sig("cpt_tracer_counters", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_stack_overflows", C.c_int, [_vp, _vp])
 _sig("cpt_tracer_reset_counters", C.c_int, [_vp])
 _sig("cpt_tracer_build_stage_ms", C.c_int, [_vp, _vp])
+_sig("cpt_tracer_build_extra_ms", C.c_int, [_vp, _vp])
 _sig("cpt_shard_samples", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp])
 _sig("cpt_comm_unique_id", C.c_int, [_vp])
 _sig("cpt_comm_create", _vp, [_vp, C.c_int, C.c_int])
@@ -380,6 +388,11 @@ class Tracer:
     def synchronize(self):
         check(lib.cpt_tracer_synchronize(self.h))
 
+    def render_one(self, d_output, width, height, spp, max_depth=0xFFFFFFFF, channel=0):
+        """kernel::PathTracer::Render: one sample (number spp, 1-based) into the device buffer, finished on return."""
+        p = RenderParams(self.h, d_output, width, height, spp, max_depth & 0xFFFFFFFF, channel)
+        check(lib.cpt_path_tracer_render(C.byref(p)))
+
     def reduce_film(self, comm, root=0, finish=True):
         """Sum of every rank's film (rendered with render_samples in sum mode) into `root`'s, over RCCL, on the
         tracer's stream; with `finish` the root's film becomes the mean (alpha 1)."""
@@ -446,7 +459,12 @@ class Tracer:
     def build_stage_ms(self):
         out = np.zeros(5, dtype=np.float32)
         check(lib.cpt_tracer_build_stage_ms(self.h, out.ctypes.data))
-        return dict(zip(["morton", "sort", "hierarchy_workgroup", "hierarchy_memory", "reserved"], out.tolist()))
+        extra = np.zeros(2, dtype=np.float32)
+        check(lib.cpt_tracer_build_extra_ms(self.h, extra.ctypes.data))
+        stages = dict(zip(["morton", "sort", "hierarchy_workgroup", "hierarchy_memory", "reserved"], out.tolist()))
+        stages["leaf_boxes"], stages["pack_records"] = float(extra[0]), float(extra[1])
+        stages["to_traversable"] = float(out.sum() + extra.sum())
+        return stages
 
 
 def shard_samples(total, rank, world, first=1):

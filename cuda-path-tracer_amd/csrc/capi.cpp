@@ -425,6 +425,16 @@ int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_co
     return Guard([&] { t->tracer->RenderSamples(spp_begin, spp_count, sum_mode != 0, d_output, width, height); return CPT_OK; });
 }
 
+int cpt_path_tracer_render(const cpt_render_params *params) {
+    if (!params || !params->scene) return Fail(CPT_ERR_INVALID, "cpt_path_tracer_render: null argument");
+    if (!params->output || params->screen_width == 0 || params->screen_height == 0 || params->spp == 0 || params->channel < 0 || params->channel > 1)
+        return Fail(CPT_ERR_INVALID, "cpt_path_tracer_render: bad parameter block");
+    return Guard([&] {
+        params->scene->tracer->RenderOneSample(params->output, params->screen_width, params->screen_height, params->spp, params->max_depth, params->channel);
+        return CPT_OK;
+    });
+}
+
 float *cpt_tracer_film_device_ptr(cpt_tracer *t) {
     if (!t) return nullptr;
     t->tracer->NoteFilmExposed();
@@ -531,6 +541,13 @@ int cpt_tracer_reset_counters(cpt_tracer *t) {
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]) {
     TRACER_OR_FAIL(t);
     memcpy(out5, t->tracer->BuildStageMs(), 5 * sizeof(float));
+    return CPT_OK;
+}
+int cpt_tracer_build_extra_ms(cpt_tracer *t, float out2[2]) {
+    TRACER_OR_FAIL(t);
+    if (!out2) return Fail(CPT_ERR_INVALID, "cpt_tracer_build_extra_ms: null argument");
+    out2[0] = t->tracer->LeafBoxesMs();
+    out2[1] = t->tracer->PackMs();
     return CPT_OK;
 }
 

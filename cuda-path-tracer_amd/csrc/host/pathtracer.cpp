@@ -103,6 +103,8 @@ void PathTracer::BuildAccel() {
     mesh_index_.clear();
     instance_mesh_.clear();
     memset(build_stage_ms_, 0, sizeof(build_stage_ms_));
+    leaf_boxes_ms_ = pack_ms_ = 0.0f;
+    largest_mesh_ = (size_t)-1;
     uint32_t largest = 0;
 
     std::vector<cpt::Bbox> leaf_bboxes;
@@ -129,16 +131,30 @@ void PathTracer::BuildAccel() {
             leaf_scratch_.Allocate(sizeof(cpt::Bbox) * (size_t)n);
 
             // leaf boxes on the device (the reference loops over triangles on the host, mesh.cpp:88-98)
+            const bool timed = profile_build_ && n >= largest;
+            hipEvent_t box_ev[2] = {nullptr, nullptr};
+            if (timed) {
+                for (auto &e : box_ev) CPT_HIP(hipEventCreate(&e));
+                CPT_HIP(hipEventRecord(box_ev[0], stream_));
+            }
             rc_check(cpt::lbvh_triangle_boxes(leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->indices.TypedGpuData<uint32_t>(),
                                               mb->positions.TypedGpuData<V3>(), n, stream_), "triangle boxes");
             const struct Bbox &hb = mesh->Bbox();
             cpt::Bbox merged{V4{hb.pmin.x, hb.pmin.y, hb.pmin.z, 1.0f}, V4{hb.pmax.x, hb.pmax.y, hb.pmax.z, 1.0f}};
-            bool profile = profile_build_ && n >= largest;
+            if (timed) CPT_HIP(hipEventRecord(box_ev[1], stream_));
+            bool profile = timed;
             float stage[5];
             rc_check(cpt::lbvh_build(mb->nodes.TypedGpuData<cpt::AccelNode>(), mb->bboxes.TypedGpuData<cpt::Bbox>(), merged, n, stream_, &workspace_,
                                      leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->keys.TypedGpuData<uint64_t>(), nullptr, profile ? stage : nullptr),
                      "bottom-level build");
-            if (profile) { memcpy(build_stage_ms_, stage, sizeof(stage)); largest = n; }
+            if (profile) {
+                memcpy(build_stage_ms_, stage, sizeof(stage));
+                largest = n;
+                largest_mesh_ = meshes_.size();
+                CPT_HIP(hipEventSynchronize(box_ev[1]));
+                CPT_HIP(hipEventElapsedTime(&leaf_boxes_ms_, box_ev[0], box_ev[1]));
+            }
+            for (auto &e : box_ev) if (e) (void)hipEventDestroy(e);
             found = mesh_index_.emplace(mesh, (uint32_t)meshes_.size()).first;
             meshes_.push_back(std::move(mb));
         }
@@ -170,6 +186,21 @@ void PathTracer::BuildAccel() {
     for (size_t i = 0; i < meshes_.size(); i++) {
         MeshBuffers &mb = *meshes_[i];
         cpt::AccelRoot *root = &mesh_table_.TypedGpuData<cpt::MeshDev>()[i].root;
+        const bool timed = profile_build_ && i == largest_mesh_;
+        hipEvent_t pack_ev[2] = {nullptr, nullptr};
+        if (timed) {
+            for (auto &e : pack_ev) CPT_HIP(hipEventCreate(&e));
+            CPT_HIP(hipEventRecord(pack_ev[0], stream_));
+        }
+        struct PackTimer {               // closes the measurement when the iteration ends
+            hipEvent_t *ev; hipStream_t stream; float *out; bool on;
+            ~PackTimer() {
+                if (!on) return;
+                if (hipEventRecord(ev[1], stream) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess) (void)hipEventElapsedTime(out, ev[0], ev[1]);
+                (void)hipEventDestroy(ev[0]);
+                (void)hipEventDestroy(ev[1]);
+            }
+        } pack_timer{pack_ev, stream_, &pack_ms_, timed};
         rc_check(cpt::lbvh_pack(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.tris.TypedGpuData<cpt::TriRecord>(), root,
                                 mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles,
                                 mb.indices.TypedGpuData<uint32_t>(), mb.positions.TypedGpuData<V3>(), stream_), "pack bottom level");
@@ -468,6 +499,24 @@ void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode
     p.sum_mode = sum_mode ? 1 : 0;
     p.spp = spp_begin;
     LaunchSamples(p, count);
+}
+
+// kernel::PathTracer::Render(const Params &) (src/kernels/integrator/path.cu:109-115): one sample per pixel with the
+// values of the call, into `output`, finished on return; the tracer's own settings and sample counter are not touched
+void PathTracer::RenderOneSample(float *output, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, int channel) {
+    if (!built_ || !has_camera_ || instance_mesh_.empty()) throw std::runtime_error("PathTracer::RenderOneSample before BuildBuffers produced a scene");
+    if (!output || width == 0 || height == 0 || spp == 0) throw std::invalid_argument("PathTracer::RenderOneSample: bad argument");
+    RefreshEdits();
+    cpt::RenderParams p;
+    p.output = output;
+    p.width = width;
+    p.height = height;
+    p.spp = spp;
+    p.max_depth = max_depth;
+    p.channel = channel;
+    p.sum_mode = 0;
+    LaunchSample(p);
+    CPT_HIP(hipStreamSynchronize(stream_));
 }
 
 void PathTracer::Synchronize() {

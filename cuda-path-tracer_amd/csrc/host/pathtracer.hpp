@@ -60,6 +60,10 @@ public:
     // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
     void RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height);
     // rays, node records, triangle records, paths, shading surfaces, traversal stack entries dropped (0 = all traversals complete)
+    // One sample per pixel exactly as kernel::PathTracer::Render(const Params &) takes it (src/kernels/integrator/path.cuh:8-22):
+    // device `output` of width * height float4 (running mean, row 0 = top), 1-based sample number, max_depth as passed to the
+    // kernel (0xffffffff = unbounded), channel 0 colour / 1 normal.  Blocks until the sample is in the buffer.
+    void RenderOneSample(float *output, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, int channel);
     void ReadCounters(unsigned long long out[6]);
     // `count` Update() calls bracketed by events on the tracer's stream; returns device milliseconds
     float UpdateTimed(uint32_t count);
@@ -75,6 +79,10 @@ public:
     // (morton, sort, gather, karras, refit), valid after SetProfileBuild(true)
     void SetProfileBuild(bool on) { profile_build_ = on; }
     const float *BuildStageMs() const { return build_stage_ms_; }
+    // the same mesh's triangle-box kernel before the build and record-packing kernels after it: what has to run besides
+    // the build before a ray can be traced
+    float LeafBoxesMs() const { return leaf_boxes_ms_; }
+    float PackMs() const { return pack_ms_; }
 
     // Looks for edits made to the scene's materials (Material::SetChanged) and camera since the device tables were
     // written, re-uploads what moved and restarts the accumulation; Update and UpdateMany call it.  Returns whether
@@ -127,6 +135,8 @@ private:
     bool resident_fast_ = false;
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
+    float leaf_boxes_ms_ = 0.0f, pack_ms_ = 0.0f;
+    size_t largest_mesh_ = (size_t)-1;
 
     cpt::BuildWorkspace workspace_;
     std::vector<std::unique_ptr<MeshBuffers>> meshes_;

@@ -191,6 +191,23 @@ uint32_t cpt_tracer_num_lights(const cpt_tracer *t);
  * mean.  d_output (W*H*4 floats) may be NULL to use the tracer's film.  Asynchronous. */
 int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_count, int sum_mode, float *d_output, uint32_t width,
                               uint32_t height);
+/* Replaces: static void kernel::PathTracer::Render(const Params &)   src/kernels/integrator/path.cuh:8-22, path.cu:109-115,
+ * at its own level: a parameter block by value-like struct, exactly ONE sample per pixel into `output` (running mean with the
+ * sample number `spp`, as RenderKernel accumulates, path.cu:99-104), and the call returns when the sample is in the buffer
+ * (the reference synchronises the device and asserts).  `scene` stands for Params::scene: the device-side camera, light table,
+ * instances and top-level BVH that cpt_tracer_build_buffers made (the reference fills Params::scene from the same
+ * BuildBuffers, src/pathtracer/pathtracer.cpp:37-50).  The tracer's own settings, film and sample counter are not touched. */
+typedef struct cpt_render_params {
+    cpt_tracer *scene;
+    float *output;               /* device memory, screen_width * screen_height * 4 floats, row 0 = top of the image */
+    uint32_t screen_width;
+    uint32_t screen_height;
+    uint32_t spp;                /* 1-based number of this sample */
+    uint32_t max_depth;          /* 0xffffffff = unbounded, what PathTracer::Update passes for -1 (pathtracer.cpp:56) */
+    int channel;                 /* 0 = eColor, 1 = eNormal */
+} cpt_render_params;
+int cpt_path_tracer_render(const cpt_render_params *params);
+
 float *cpt_tracer_film_device_ptr(cpt_tracer *t);                   /* Film::CudaMap */
 int cpt_tracer_film_read(cpt_tracer *t, float *rgba);               /* synchronises */
 int cpt_tracer_film_save(cpt_tracer *t, const char *path);          /* Film::SaveTo: fp32 RGBA OpenEXR */
@@ -218,6 +235,10 @@ int cpt_tracer_counters(cpt_tracer *t, uint64_t out5[5]);
 int cpt_tracer_stack_overflows(cpt_tracer *t, uint64_t *count);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
+/* With cpt_tracer_set_profile_build: device milliseconds of the kernels that frame the largest mesh's build before a ray can
+ * be traced: out2[0] the per-triangle leaf boxes (src/scene/mesh.cpp:88-98 computes them on the host), out2[1] packing nodes
+ * and triangles into traversal records.  Build + these two = time to a traversable BVH. */
+int cpt_tracer_build_extra_ms(cpt_tracer *t, float out2[2]);
 
 /* ---- several GPUs of one node -----------------------------------------------------------------
  * No counterpart in the reference, which renders on one GPU (nothing under src/ selects a device).  The sampler is

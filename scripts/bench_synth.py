@@ -56,7 +56,8 @@ for spec in modes.split(","):
     if tail:
         tr.set_wavefront_tail(int(tail))
     tr.reset()
-    tr.update(2); tr.synchronize(); tr.reset_counters()
+    tr.update(spp); tr.synchronize(); tr.reset_counters()      # warm-up with the launch shape of the timed run
+    tr.reset()
     ms = tr.update_timed(spp)
     c = tr.counters()
     print(f"path tracing depth {depth} integrator {spec}: {ms/spp:.3f} ms/spp, {W*H*spp/ms/1e3:.1f} Mpaths/s, {c['rays']/ms/1e3:.1f} Mrays/s, rays/path {c['rays']/c['paths']:.2f}, "

@@ -22,7 +22,7 @@ for trav in 0 1; do
   bash scripts/pmc_passes.sh "$out/pmc_hf10m_$name" python3 scripts/bench_synth.py heightfield 10000000 3840 2160 32 5 4 $trav 32
   python3 scripts/pmc_summary.py "$out/pmc_hf10m_$name" k_render_flow > "$out/pmc_hf10m_${name}_k_render_flow.txt"
   python3 scripts/pmc_summary.py "$out/pmc_hf10m_$name" k_first_hit > "$out/pmc_hf10m_${name}_k_first_hit.txt"
-  python3 scripts/pmc_to_json.py "$out/pmc_hf10m_$name" k_render_flow "k_render_flow/heightfield-10m/$name" 32 "$J" "scripts/bench_synth.py heightfield 10000000 3840 2160 32 5 4 $trav 32 (dispatches of 2 and 32 samples pooled: per-sample values)"
+  python3 scripts/pmc_to_json.py "$out/pmc_hf10m_$name" k_render_flow "k_render_flow/heightfield-10m/$name" 32 "$J" "scripts/bench_synth.py heightfield 10000000 3840 2160 32 5 4 $trav 32 (two dispatches of 32 samples)"
   python3 scripts/pmc_to_json.py "$out/pmc_hf10m_$name" k_first_hit "k_first_hit/heightfield-10m/$name" 1 "$J" "same run: 8.3M camera rays per dispatch"
   echo "10M $name counters done"
 done

@@ -430,3 +430,33 @@ def test_material_and_camera_edits_restart_the_render(cpt):
     # no edit: the accumulation goes on
     tr.update(2)
     assert cpt.lib.cpt_tracer_current_spp(tr.h) == 5
+
+
+def test_render_entry_point_at_the_kernel_level(cpt):
+    """cpt_path_tracer_render is kernel::PathTracer::Render(const Params &) (/root/reference/src/kernels/integrator/path.cuh:22):
+    a parameter block, one sample per call into a caller-owned device buffer, running mean by sample number, finished on
+    return.  Called as PathTracer::Update calls the reference's (pathtracer.cpp:37-59) it leaves the film of Update itself,
+    bit for bit, and the oracle's image; the tracer's own state is untouched."""
+    objs, cam = cornell(glass=True)
+    W, H = 72, 40
+    sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=6)
+    out = cpt.DeviceArray((H, W, 4), np.float32)
+    out.zero()
+    for spp in range(1, 9):
+        tr.render_one(out.ptr, W, H, spp, max_depth=6, channel=0)
+    img = out.to_host()                                   # no synchronise: the call returns when the sample is there
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 0
+    tr.update(8)
+    assert np.array_equal(img.view(np.uint32), tr.film().view(np.uint32))
+    ref, _ = OracleScene(objs, cam).render(W, H, 1, 9, 6)
+    compare(img, ref)
+    # unbounded depth as the reference passes it, and the normal channel
+    out.zero()
+    tr.render_one(out.ptr, W, H, 1, max_depth=0xFFFFFFFF, channel=1)
+    nrm = out.to_host()
+    ref_n, _ = OracleScene(objs, cam).render(W, H, 1, 2, -1, channel=1)
+    assert np.allclose(nrm, ref_n, atol=1e-6)
+    with pytest.raises(cpt.CptError):
+        tr.render_one(None, W, H, 1)
+    with pytest.raises(cpt.CptError):
+        tr.render_one(out.ptr, W, H, 0)
