@@ -272,11 +272,29 @@ def main():
     fast = 1 if args.traversal == "fast" else 0
 
     comm = None
+    comm_note = ""
     if world > 1 and not rehearse:
         # the communicator id travels by torch.distributed; everything after that is the library's own RCCL use
-        ident = [cpt.Comm.unique_id() if rank == 0 else None]
+        ident = [None]
+        if rank == 0:
+            try:
+                ident = [cpt.Comm.unique_id()]
+            except Exception as e:                       # librccl could not be opened: say so and reduce through torch.distributed instead
+                ident = [repr(e)]
         dist.broadcast_object_list(ident, src=0)
-        comm = cpt.Comm(ident[0], rank, world)
+        ok = torch.tensor([0], dtype=torch.int32, device=device)
+        if isinstance(ident[0], bytes):
+            try:
+                comm = cpt.Comm(ident[0], rank, world)
+                ok += 1
+            except Exception as e:
+                comm_note = repr(e)
+        else:
+            comm_note = str(ident[0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:                          # all ranks or none
+            comm = None
+            comm_note = "library communicator unavailable (" + (comm_note or "another rank failed") + "): films reduced by torch.distributed"
 
     def barrier():
         if world > 1:
@@ -303,11 +321,16 @@ def main():
         tracer.render_samples(begin, count, True)
         if comm is not None:
             tracer.reduce_film(comm, root=0, finish=finish)
-        elif world > 1:                                 # rehearsal: same blocks, the sum over gloo on the host
+        elif world > 1 and rehearse:                    # rehearsal: same blocks, the sum over gloo on the host
             tracer.synchronize()
             host = torch.from_numpy(tracer.film())
             sharding.reduce_sum_to_root(host, dst=0)
             return host.numpy()
+        elif world > 1:                                 # fallback only: the films as torch tensors, summed by torch.distributed
+            tracer.synchronize()
+            dev = torch.from_numpy(tracer.film()).to(device)
+            sharding.reduce_sum_to_root(dev, dst=0)
+            return dev.cpu().numpy()
         return None
 
     # ------------------------------------------------------------------ headline workload
@@ -385,7 +408,7 @@ def main():
             "config": {"workload": f"{workload}, 1 spp per step, {K} spp per GPU", "traversal": args.traversal,
                        "samples_per_launch": per_launch, "integrator": INTEGRATOR_NAME[integrator],
                        "sharding": "replicas only" if world == 1 else f"{world} x disjoint sample blocks, one ncclReduce of the {W * H * 16 / 1e6:.1f} MB films issued by the library"
-                       if comm is not None else f"{world} ranks rehearsed on one GPU, sum over gloo"},
+                       if comm is not None else (f"{world} ranks rehearsed on one GPU, sum over gloo" if rehearse else comm_note)},
             "mrays_per_s": round(total["rays"] / elapsed / 1e6, 3),
             "rays_per_path": round(total["rays"] / max(total["paths"], 1), 4),
         }

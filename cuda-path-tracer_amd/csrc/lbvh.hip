@@ -610,7 +610,7 @@ __device__ inline void store_box_sc1(Bbox *p, f32x4 lo, f32x4 hi) {
 // loads of the sibling box.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSlotValid = 0x80000000u;
-constexpr int kUpBlock = 512;              // leaves per workgroup of the bottom-up pass
+constexpr int kUpBlock = 512;              // leaves per workgroup of the bottom-up pass (256 / 512 / 1024 measured: 0.161 / 0.163 / 0.189 ms for the 1M build)
 
 __device__ inline int wave_incl_min(int v) {
     int lane = threadIdx.x & 63;
