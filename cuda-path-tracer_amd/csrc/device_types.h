@@ -63,7 +63,14 @@ struct InstanceDev {
     uint32_t material;
     int32_t light;       // index into the light table or -1
     uint32_t tlas_position;  // position of the instance among the sorted leaves of the top-level BVH (the reference visits leaves in descending position)
+    uint32_t flags;          // kInstanceIdentity
+    uint32_t pad[3];
 };
+// transform_inv is the identity matrix up to the signs of its zeros (what the inverse of an untransformed object's matrix
+// comes out as).  Its product with a finite point or direction returns every component that is not zero unchanged,
+// and a zero as a zero of some sign, so the traversal may enter such an instance without the two matrix products
+// whenever the signs of zeros cannot matter.
+constexpr uint32_t kInstanceIdentity = 1u;
 
 enum BsdfType : int { kLambert = 0, kPhong = 1, kBlinnPhong = 2, kMicrofacet = 3, kGlass = 4 };   // src/kernels/bsdf/bsdf.cuh:14-20
 enum LobeType : int { kLobeNone = 0, kLobeDiffuse = 1, kLobeGlossy = 2, kLobeSpecular = 3 };      // src/kernels/bsdf/common.cuh:8-13

@@ -67,6 +67,9 @@ struct Flow {
         const bool is_inst = alive && (cur & kLeafBit) && !in_blas;
         const int cn = lanes_in(__ballot(is_node)), ct = lanes_in(__ballot(is_tri)), ci = lanes_in(__ballot(is_inst));
         bool need_pop = false;
+#ifdef CPT_STEP_STATS
+        const unsigned long long stat_t0 = clock64();
+#endif
         if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
             if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
@@ -82,10 +85,13 @@ struct Flow {
                     if (hl || hr) cur = (hl && (left_first || !hr)) ? lc : rc;
                     else need_pop = true;
                 } else {
-                    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l);
-                    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r);
-                    if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
-                    if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                    // accel.cuh:84-91 pushes a left child that is hit and tests its entry distance against the reach when it
+                    // is popped; the reach only shrinks, so one that is out of reach now never needs the stack, and one
+                    // that would be popped at once (the right child is not walked) is walked without going through it
+                    const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, kRayTMin, t0l) && t0l < tmax;
+                    const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, kRayTMin, t0r) && t0r < tmax;
+                    if (hl && hr) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                    if (hl || hr) cur = __float_as_uint(hr ? q3.y : q3.x);
                     else need_pop = true;
                 }
             }
@@ -126,7 +132,6 @@ struct Flow {
             if (is_inst) {
                 inst_id = cur & ~kLeafBit;
                 const InstanceDev &in = sc.instances[inst_id];
-                M4 inv = in.transform_inv;
                 const MeshDev &m = sc.meshes[in.mesh];
                 nodes = m.nodes;
                 tris = m.tris;
@@ -134,7 +139,7 @@ struct Flow {
                 if constexpr (FAST) inst_pos = in.tlas_position;
                 V3 ow, dw;
                 world(ow, dw);
-                f.set_for<FAST>(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), r.flags == 0);
+                enter_instance<FAST>(f, in, ow, dw, world_r, world_fast, r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
@@ -142,6 +147,10 @@ struct Flow {
                 else need_pop = true;
             }
         }
+#ifdef CPT_STEP_STATS
+        const unsigned long long stat_t1 = clock64();
+        const int stat_pops = lanes_in(__ballot(need_pop));
+#endif
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
@@ -152,6 +161,14 @@ struct Flow {
                 if (within_reach<FAST>(__uint_as_float(e.y), tmax, any)) { cur = e.x; break; }
             }
         }
+#ifdef CPT_STEP_STATS
+        if (cnt.stats && cn + ct + ci != 0) {
+            const unsigned long long stat_t2 = clock64();
+            const int kind = (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) ? 0 : (ct >= ci ? 1 : 2);
+            cnt.stats->time[kind] += stat_t1 - stat_t0; cnt.stats->trips[kind]++; cnt.stats->lanes[kind] += kind == 0 ? cn : kind == 1 ? ct : ci;
+            cnt.stats->time[3] += stat_t2 - stat_t1; cnt.stats->trips[3] += stat_pops != 0; cnt.stats->lanes[3] += stat_pops;
+        }
+#endif
         return cn + ct + ci != 0;
     }
 };

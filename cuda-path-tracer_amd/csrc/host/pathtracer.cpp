@@ -271,6 +271,12 @@ void PathTracer::BuildInstancesAndLights() {
         inst.transform = object.GetTransform();
         inst.transform_inv = InverseTransform(inst.transform);
         inst.transform_it = cpt::transpose(inst.transform_inv);
+        {
+            const float *m = &inst.transform_inv.c[0].x;
+            bool identity = true;
+            for (int k = 0; k < 16; k++) identity = identity && (k % 5 == 0 ? m[k] == 1.0f : m[k] == 0.0f);
+            if (identity) inst.flags |= cpt::kInstanceIdentity;
+        }
         inst.mesh = instance_mesh_[slot];
         inst.material = found->second;
         inst.light = -1;

@@ -603,11 +603,16 @@ __device__ inline void store_box_sc1(Bbox *p, f32x4 lo, f32x4 hi) {
 //
 // A split whose parent covers only leaves of one workgroup is exchanged through LDS.  Both
 // children must take the same decision knowing only their own half of the parent's range, so
-// the workgroup precomputes it per split from the 257 prefix lengths it can see: the parent of
-// split g stays inside the workgroup's leaves [b0, b1] iff some d(j) < d(g) with b0-1 <= j < g and
-// some d(j) < d(g) with g < j <= b1 (two running minima).  All other splits use memory:
-// device-scope write-through stores of the child box, a device-scope exchange, and device-scope
-// loads of the sibling box.
+// the workgroup precomputes it per split from the prefix lengths it can see (one more than it has
+// leaves): the parent of split g stays inside the workgroup's leaves [b0, b1] iff some d(j) < d(g)
+// with b0-1 <= j < g and some d(j) < d(g) with g < j <= b1 (two running minima); the exchange word
+// of every other split starts as a marker that sends the child to the memory pass.  Inside the
+// workgroup a node is a pair of leaf positions with the two prefix lengths just outside it, and the
+// exchange word carries the far end together with the prefix length beyond it, so a level is one
+// LDS exchange and one 32-byte LDS read (the pass is bound by its gather of the leaf boxes: with
+// random primitive order a 32-byte read per leaf moves a whole memory line).  All other splits use
+// memory: device-scope write-through stores of the child box, a device-scope exchange, and
+// device-scope loads of the sibling box.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSlotValid = 0x80000000u;
 constexpr int kUpBlock = 512;              // leaves per workgroup of the bottom-up pass (256 / 512 / 1024 measured: 0.161 / 0.163 / 0.189 ms for the 1M build)
@@ -727,6 +732,10 @@ __global__ void __launch_bounds__(kBlock) k_climb(const Carrier *__restrict__ ca
     climb_global<PARENTS>(c.l, c.r, c.idx, lo, hi, true, a4.w, b4.w, keys, bboxes, nodes, parents, slots, merged, n);
 }
 
+// LDS exchange word of a split inside a workgroup: bit 31 = a child has arrived, bits 16-23 = the prefix length
+// beyond that child's far end plus one, bits 0-15 = the far end as a leaf position of the workgroup.
+constexpr uint32_t kSlotGlobal = 0x40000000u;       // initial word of a split whose parent spans several workgroups
+
 template <bool PARENTS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__ keys, const Bbox *__restrict__ leaf_src, Bbox *bboxes, AccelNode *nodes,
                                                     uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, uint32_t carrier_limit, Bbox merged, uint32_t n) {
@@ -736,14 +745,14 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
     __shared__ int s_delta[BLOCK + 1];           // d(b0-1) .. d(b1)
     __shared__ int s_wave_min[2][BLOCK / 64];
     __shared__ int s_lmin[BLOCK], s_rmin[BLOCK + 2];
-    __shared__ uint8_t s_local[BLOCK];           // split b0+t: the parent stays inside this workgroup
-    __shared__ uint32_t s_slot[BLOCK];           // exchange words of those splits
-    __shared__ uint32_t s_box[BLOCK][6];         // boxes (order keys) of internal nodes b0 .. b1
-    __shared__ uint2 s_children[BLOCK];          // their children; rc == 0 marks a node this workgroup did not finish
-    __shared__ uint32_t s_leaf[BLOCK][6];        // boxes (order keys) of this workgroup's leaves
+    __shared__ uint32_t s_slot[BLOCK + 1];       // exchange word of split b0-1+k
+    // Entry e < BLOCK: internal node b0+e; entry BLOCK+e: leaf b0+e.  (lo.xyz, hi.x) (hi.yz, left child, right child):
+    // boxes as order keys, children as entry numbers; a right child of 0 marks a node this workgroup did not finish.
+    __shared__ uint4 s_node[2 * BLOCK][2];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t b0 = blockIdx.x * BLOCK;
     const uint32_t i = b0 + t;
+    auto global_id = [&](uint32_t e) { return e < (uint32_t)BLOCK ? b0 + e : (n - 1) + b0 + (e - BLOCK); };
 
     // ---- keys, leaf gather (accel_build.cu:43-51 and the payload permutation of :193)
     uint64_t key = 0;
@@ -759,14 +768,13 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
         nodes[(n - 1) + i] = AccelNode{prim, ~0u};
         lo[0] = order_key(a.x); lo[1] = order_key(a.y); lo[2] = order_key(a.z);
         hi[0] = order_key(b.x); hi[1] = order_key(b.y); hi[2] = order_key(b.z);
-        uint32_t *sl = s_leaf[t];
-        sl[0] = lo[0]; sl[1] = lo[1]; sl[2] = lo[2]; sl[3] = hi[0]; sl[4] = hi[1]; sl[5] = hi[2];
+        s_node[BLOCK + t][0] = make_uint4(lo[0], lo[1], lo[2], hi[0]);
+        s_node[BLOCK + t][1] = make_uint4(hi[1], hi[2], 0u, 0u);
     }
+    s_node[t][1] = make_uint4(0u, 0u, 0u, 0u);
     s_key[t + 1] = key;
     if (t == 0) s_key[0] = b0 > 0 ? keys[b0 - 1] : 0ull;
     if (t == 1) s_key[BLOCK + 1] = (b0 + BLOCK < n) ? keys[b0 + BLOCK] : 0ull;
-    s_slot[t] = 0;
-    s_children[t] = make_uint2(0u, 0u);
     if (t == 0) s_park_count = 0;
     __syncthreads();
     // d(j) for j = b0-1+k, k = 0 .. BLOCK: -1 outside the key array
@@ -794,106 +802,91 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
     {
         // split g = b0 + t has d(g) = window entry t+1; left candidates are entries 0..t, right ones t+2..BLOCK
         const int dg = s_delta[t + 1];
-        s_local[t] = (dg >= 0 && s_lmin[t] < dg && s_rmin[t + 2] < dg) ? 1 : 0;
+        s_slot[t + 1] = (dg >= 0 && s_lmin[t] < dg && s_rmin[t + 2] < dg) ? 0u : kSlotGlobal;
+        if (t == 0) s_slot[0] = kSlotGlobal;
     }
     __syncthreads();
 
-    // d(j1 - 1): prefix shared by sorted keys j1-1 and j1
-    auto delta_before = [&](uint32_t j1) -> int {
-        if (j1 == 0 || j1 >= n) return -1;
-        const uint32_t k = j1 - b0;                         // window entry of j = j1 - 1
-        if (k <= (uint32_t)BLOCK) return s_delta[k];
-        return (int)lcp(keys[j1 - 1], keys[j1]);
-    };
-    const uint32_t init_lo[3] = {order_key(merged.pmax.x), order_key(merged.pmax.y), order_key(merged.pmax.z)};
-    const uint32_t init_hi[3] = {order_key(merged.pmin.x), order_key(merged.pmin.y), order_key(merged.pmin.z)};
-    auto box_lo = [&]() { return make_float4(key_to_float(min(init_lo[0], lo[0])), key_to_float(min(init_lo[1], lo[1])), key_to_float(min(init_lo[2], lo[2])), merged.pmax.w); };
-    auto box_hi = [&]() { return make_float4(key_to_float(max(init_hi[0], hi[0])), key_to_float(max(init_hi[1], hi[1])), key_to_float(max(init_hi[2], hi[2])), merged.pmin.w); };
-    uint32_t l = i, r = i, lc = 0, rc = 0;
-    bool internal = false;
-    while (i < n) {
-        if (l == 0 && r == n - 1) {                       // the root is node 0
-            nodes[0] = AccelNode{lc, rc};
-            if (PARENTS) { parents[lc] = 0; parents[rc] = 0; }
-            float4 *gb = reinterpret_cast<float4 *>(bboxes);
-            gb[0] = box_lo();
-            gb[1] = box_hi();
-            break;
-        }
-        const bool left_child = delta_before(r + 1) > delta_before(l);
-        const uint32_t g = left_child ? r : l - 1;
-        const uint32_t idx = internal ? (left_child ? r : l) : (n - 1) + i;
-        const uint32_t gs = g - b0;
-        // A finished internal node leaves record and box in LDS (its number lies in this workgroup's
-        // range because its keys do); all of them are written to memory together after the climb, by
-        // every lane and in index order, instead of one scattered store per level by the few lanes
-        // that are still climbing.
+    // ---- the climb inside the workgroup.  A lane holds a node as leaf positions [lr, rr] of this workgroup with the
+    // prefix lengths just outside the range (dl, dr: window entries lr and rr + 1); while the parent is a split of this
+    // workgroup both stay inside the window, and the exchange word hands the sibling's far end and the prefix
+    // length beyond it to the lane that goes on, so a level costs one exchange and one 32-byte LDS read.
+    uint32_t lr = t, rr = t, me = BLOCK + t, lc = 0, rc = 0;
+    int dl = s_delta[t], dr = s_delta[t + 1];
+    bool internal = false, overflow = false;
+    if (i < n) for (;;) {
+        const bool left_child = dr > dl;
+        // A finished internal node leaves record and box in LDS (its number lies in this workgroup's range because its
+        // keys do); all of them are written to memory together after the climb, by every lane and in index order,
+        // instead of one scattered store per level by the few lanes that are still climbing.
         if (internal) {
-            s_children[idx - b0] = make_uint2(lc, rc);
-            uint32_t *sb = s_box[idx - b0];
-            sb[0] = lo[0]; sb[1] = lo[1]; sb[2] = lo[2]; sb[3] = hi[0]; sb[4] = hi[1]; sb[5] = hi[2];
+            me = left_child ? rr : lr;
+            s_node[me][0] = make_uint4(lo[0], lo[1], lo[2], hi[0]);
+            s_node[me][1] = make_uint4(hi[1], hi[2], lc, rc);
         }
-        if (!(gs < (uint32_t)BLOCK && s_local[gs] != 0)) {
-            // The parent spans several workgroups.  The node meets its sibling in the second pass,
-            // which starts after this kernel has ended, so that the memory round trips of that
-            // exchange do not stall the lanes of this wave that still work in LDS.
+        if ((dl & dr) < 0) break;                          // both are -1: the root, node 0 (written with the others)
+        const uint32_t gs = left_child ? rr + 1 : lr;
+        const uint32_t word = kSlotValid | ((uint32_t)((left_child ? dl : dr) + 1) << 16) | (left_child ? lr : rr);
+        // LDS executes a wave's operations in issue order, so the record written above is in place when another wave
+        // sees the exchange and reads it afterwards; only the compiler has to be kept from moving the accesses.
+        asm volatile("" ::: "memory");
+        const uint32_t prev = __hip_atomic_exchange(&s_slot[gs], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (prev == 0) break;                              // the sibling goes on from here
+        if (prev == kSlotGlobal) {
+            // The parent spans several workgroups.  The node meets its sibling in the second pass, which starts after
+            // this kernel has ended, so that the memory round trips of that exchange do not stall the lanes of this
+            // wave that still work in LDS.
             const uint32_t slot = atomicAdd(&s_park_count, 1u);
-            if (slot < carrier_limit) {
-                s_park[slot] = Carrier{l, r, idx, 0u};
-            } else {                                      // no room: climb from here, through memory
-                float lw = merged.pmax.w, hw = merged.pmin.w;
-                if (!internal) {
-                    const float4 *own = reinterpret_cast<const float4 *>(leaf_src + (uint32_t)key);
-                    lw = own[0].w; hw = own[1].w;
-                } else {                                  // the stored box is the folded one
-                    for (int a = 0; a < 3; a++) { lo[a] = min(init_lo[a], lo[a]); hi[a] = max(init_hi[a], hi[a]); }
-                }
-                climb_global<PARENTS>(l, r, idx, lo, hi, false, lw, hw, keys, bboxes, nodes, parents, slots, merged, n);
-            }
+            if (slot < carrier_limit) s_park[slot] = Carrier{b0 + lr, b0 + rr, global_id(me), 0u};
+            else overflow = true;                          // no room: climbs through memory at the end of this kernel
             break;
         }
-        // LDS executes a wave's operations in issue order, so the box written above is in place
-        // when another wave sees the exchange and reads it afterwards; only the compiler has to
-        // be kept from moving the accesses.  (An acquire/release exchange would also wait for
-        // the global stores above, a round trip to memory per level of the climb.)
-        const uint32_t far = (left_child ? l : r) | kSlotValid;
-        asm volatile("" ::: "memory");
-        const uint32_t prev = __hip_atomic_exchange(&s_slot[gs], far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-        if (prev == 0) break;
-        const uint32_t sib_far = prev & ~kSlotValid;
+        const uint32_t sib_far = prev & 0xffffu;
+        const int d_far = (int)((prev >> 16) & 0xffu) - 1;
         uint32_t sib;
-        if (left_child) {                                  // sibling = right child, keys [g+1, sib_far]
-            sib = sib_far == g + 1 ? (n - 1) + g + 1 : g + 1;
-            lc = idx; rc = sib; r = sib_far;
-        } else {                                           // sibling = left child, keys [sib_far, g]
-            sib = sib_far == g ? (n - 1) + g : g;
-            lc = sib; rc = idx; l = sib_far;
+        if (left_child) {                                  // sibling = right child, leaves [rr + 1, sib_far]
+            sib = rr + 1;
+            if (sib_far == sib) sib += BLOCK;
+            lc = me; rc = sib; rr = sib_far; dr = d_far;
+        } else {                                           // sibling = left child, leaves [sib_far, lr - 1]
+            sib = lr - 1;
+            if (sib_far == sib) sib += BLOCK;
+            lc = sib; rc = me; lr = sib_far; dl = d_far;
         }
-        const uint32_t *sb = sib >= n - 1 ? s_leaf[sib - (n - 1) - b0] : s_box[sib - b0];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            lo[a] = min(lo[a], sb[a]);
-            hi[a] = max(hi[a], sb[3 + a]);
-        }
+        const uint4 a = s_node[sib][0], b = s_node[sib][1];
+        lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+        hi[0] = max(hi[0], a.w); hi[1] = max(hi[1], b.x); hi[2] = max(hi[2], b.y);
         internal = true;
     }
     __syncthreads();
+    const uint32_t init_lo[3] = {order_key(merged.pmax.x), order_key(merged.pmax.y), order_key(merged.pmax.z)};
+    const uint32_t init_hi[3] = {order_key(merged.pmin.x), order_key(merged.pmin.y), order_key(merged.pmin.z)};
     {
-        const uint2 ch = s_children[t];
-        if (ch.y != 0u) {                                   // node b0 + t was finished here (a right child is never node 0)
-            const uint32_t idx = b0 + t;
-            nodes[idx] = AccelNode{ch.x, ch.y};
-            if (PARENTS) { parents[ch.x] = idx; parents[ch.y] = idx; }
-            const uint32_t *sb = s_box[t];
+        const uint4 b = s_node[t][1];
+        if (b.w != 0u) {                                    // node b0 + t was finished here
+            const uint4 a = s_node[t][0];
+            const uint32_t idx = b0 + t, lcg = global_id(b.z), rcg = global_id(b.w);
+            nodes[idx] = AccelNode{lcg, rcg};
+            if (PARENTS) { parents[lcg] = idx; parents[rcg] = idx; }
             float4 *gb = reinterpret_cast<float4 *>(bboxes + idx);
-            gb[0] = make_float4(key_to_float(min(init_lo[0], sb[0])), key_to_float(min(init_lo[1], sb[1])), key_to_float(min(init_lo[2], sb[2])), merged.pmax.w);
-            gb[1] = make_float4(key_to_float(max(init_hi[0], sb[3])), key_to_float(max(init_hi[1], sb[4])), key_to_float(max(init_hi[2], sb[5])), merged.pmin.w);
+            gb[0] = make_float4(key_to_float(min(init_lo[0], a.x)), key_to_float(min(init_lo[1], a.y)), key_to_float(min(init_lo[2], a.z)), merged.pmax.w);
+            gb[1] = make_float4(key_to_float(max(init_hi[0], a.w)), key_to_float(max(init_hi[1], b.x)), key_to_float(max(init_hi[2], b.y)), merged.pmin.w);
         }
     }
     const uint32_t parked = min(s_park_count, carrier_limit);
     if (t < parked) carriers[(size_t)blockIdx.x * kCarriersPerGroup + t] = s_park[t];
     if (t == 0) carrier_counts[blockIdx.x] = parked;
+    if (overflow) {
+        float lw = merged.pmax.w, hw = merged.pmin.w;
+        if (!internal) {
+            const float4 *own = reinterpret_cast<const float4 *>(leaf_src + (uint32_t)key);
+            lw = own[0].w; hw = own[1].w;
+        } else {                                            // the stored box is the folded one
+            for (int a = 0; a < 3; a++) { lo[a] = min(init_lo[a], lo[a]); hi[a] = max(init_hi[a], hi[a]); }
+        }
+        climb_global<PARENTS>(b0 + lr, b0 + rr, global_id(me), lo, hi, false, lw, hw, keys, bboxes, nodes, parents, slots, merged, n);
+    }
 }
 
 // ---- packing into traversal records --------------------------------------------------------

@@ -292,6 +292,9 @@ template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5
 #endif
 constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every eighth trip
 
+#ifdef CPT_STEP_STATS
+__device__ unsigned long long g_step_stats[18];
+#endif
 template <bool MAPS, bool DENSE, bool FAST>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
@@ -306,6 +309,11 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     uint2 spill_entries[kSpillEntries];
     TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
+#ifdef CPT_STEP_STATS
+    StepStats stats;
+    cnt.stats = &stats;
+    const unsigned long long stat_begin = clock64();
+#endif
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -387,6 +395,10 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         // ---- shade: last bounce's light contribution first, then this bounce's hit.  The shadow ray goes to the
         // lane's slot of the list as soon as it is known, with what another lane needs to begin it; one that misses
         // the scene's box has nothing between the point and the light.
+#ifdef CPT_STEP_STATS
+        const unsigned long long stat_s0 = clock64();
+        stats.lanes[4] += lanes_in(__ballot(s.l.alive));
+#endif
         if (s.l.alive) {
             if (s.has_shadow) {
                 const float4 c = pool(3, threadIdx.x);
@@ -407,10 +419,17 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
                 return true;
             });
         }
+#ifdef CPT_STEP_STATS
+        stats.time[4] += clock64() - stat_s0; stats.trips[4]++;
+#endif
         const unsigned long long with_shadow = __ballot(s.l.alive && s.has_shadow);
         pool_count = __popcll(with_shadow);
         if (s.l.alive && s.has_shadow) s_order[wave_base + __popcll(with_shadow & lt_mask)] = (uint8_t)lane;
     }
+#ifdef CPT_STEP_STATS
+    stats.time[5] = clock64() - stat_begin; stats.trips[5] = 1;
+    if (lane == 0) for (int k = 0; k < 6; k++) { atomicAdd(&g_step_stats[k], stats.time[k]); atomicAdd(&g_step_stats[6 + k], stats.trips[k]); atomicAdd(&g_step_stats[12 + k], stats.lanes[k]); }
+#endif
     flush_counters(sc, cnt, paths, s_cnt);
 }
 
@@ -684,3 +703,16 @@ int launch_camera_rays(const CameraDev &cam, uint32_t W, uint32_t H, uint32_t sp
 }
 
 }  // namespace cpt
+
+#ifdef CPT_STEP_STATS
+// development build only: reads (and optionally clears) the step statistics of k_render_pool on the current device
+extern "C" __attribute__((visibility("default"))) int cpt_debug_step_stats(unsigned long long *out18, int reset) {
+    int status = (int)hipDeviceSynchronize();
+    if (status == 0 && out18) status = (int)hipMemcpyFromSymbol(out18, HIP_SYMBOL(cpt::g_step_stats), sizeof(unsigned long long) * 18);
+    if (status == 0 && reset) {
+        unsigned long long zero[18] = {};
+        status = (int)hipMemcpyToSymbol(HIP_SYMBOL(cpt::g_step_stats), zero, sizeof(zero));
+    }
+    return status;
+}
+#endif

@@ -22,7 +22,14 @@ constexpr int kLdsStackEntries = 16;   // per lane, in LDS: 16 * 8 B * 256 lanes
 constexpr int kSpillEntries = 48;      // per lane, private memory, touched only by very deep trees
 constexpr int kTraceBlock = 256;
 
+#ifdef CPT_STEP_STATS
+// Development build only (make FLAGS+=-DCPT_STEP_STATS): per wave, shader-clock time, trips and participating lanes of
+// every kind of step of the pooled megakernel (0 node, 1 triangle, 2 instance, 3 stack pops, 4 shading, 5 whole kernel).
+struct StepStats { unsigned long long time[6] = {0, 0, 0, 0, 0, 0}, trips[6] = {0, 0, 0, 0, 0, 0}, lanes[6] = {0, 0, 0, 0, 0, 0}; };
+struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; StepStats *stats = nullptr; };
+#else
 struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; };
+#endif
 
 // Per-lane stack of (node reference, entry distance) pairs.  Entry e of lane l lives at
 // lds[e * 256 + l]: lanes of a wave always touch consecutive 8-byte slots, whatever their depths.
@@ -121,6 +128,29 @@ struct RayFrame {
         if constexpr (FAST) set_recip(origin, dir); else set(origin, dir, boxes_ok);
     }
 };
+
+// The ray (ow, dw) of the world frame (reciprocal direction wr, fast division applicable: wfast) in the space of instance
+// `in` (AccelTop::Intersect, accel.cuh:131-133: origin and direction through the inverse transform).  Where the
+// inverse transform is the identity up to the signs of its zeros, the matrix products return every component that
+// is not zero unchanged and a zero as a zero whose sign depends on the matrix.  A direction the fast division
+// applies to has no zero, so it and its reciprocals are the world frame's; the origin is too unless one of its
+// components is zero, and then only its product is evaluated.  The ordered traversal makes no promise about signs
+// of zeros and keeps the world frame for every ray.
+template <bool FAST>
+__device__ inline void enter_instance(RayFrame &f, const InstanceDev &in, V3 ow, V3 dw, V3 wr, bool wfast, bool boxes_ok) {
+    if ((in.flags & kInstanceIdentity) != 0u && (FAST || wfast)) {
+        f.o = ow;
+        f.d = dw;
+        f.r = wr;
+        f.fast = FAST ? true : boxes_ok;
+        if constexpr (!FAST) {
+            if (ow.x == 0.0f || ow.y == 0.0f || ow.z == 0.0f) f.o = xyz(mul(in.transform_inv, v4(ow, 1.0f)));
+        }
+    } else {
+        const M4 inv = in.transform_inv;
+        f.set_for<FAST>(xyz(mul(inv, v4(ow, 1.0f))), xyz(mul(inv, v4(dw, 0.0f))), boxes_ok);
+    }
+}
 
 // accel.cuh:33-52 without the tmax clause; returns the entry distance in t0
 __device__ inline bool slab(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz, const RayFrame &f, float tmin, float &t0) {
@@ -318,10 +348,13 @@ struct Traversal {
                     if (hl || hr) cur = (hl && (left_first || !hr)) ? lc : rc;
                     else need_pop = true;
                 } else {
-                    bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l);
-                    bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r);
-                    if (hl) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
-                    if (hr && t0r < tmax) cur = __float_as_uint(q3.y);
+                    // accel.cuh:84-91 pushes a left child that is hit and tests its entry distance against the reach when it
+                    // is popped; the reach only shrinks, so one that is out of reach now never needs the stack, and one
+                    // that would be popped at once (the right child is not walked) is walked without going through it
+                    const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, f, tmin, t0l) && t0l < tmax;
+                    const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, f, tmin, t0r) && t0r < tmax;
+                    if (hl && hr) { st.push(sp, __float_as_uint(q3.x), t0l); sp++; }
+                    if (hl || hr) cur = __float_as_uint(hr ? q3.y : q3.x);
                     else need_pop = true;
                 }
             }
@@ -360,13 +393,12 @@ struct Traversal {
             if (is_inst) {
                 inst_id = cur & ~kLeafBit;
                 const InstanceDev &in = sc.instances[inst_id];
-                M4 inv = in.transform_inv;
                 const MeshDev &m = sc.meshes[in.mesh];
                 nodes = m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
                 if constexpr (FAST) inst_pos = in.tlas_position;
-                f.set_for<FAST>(xyz(mul(inv, v4(world.o, 1.0f))), xyz(mul(inv, v4(world.d, 0.0f))), r.flags == 0);
+                enter_instance<FAST>(f, in, world.o, world.d, world.r, world.fast, r.flags == 0);
                 in_blas = true;
                 sp_base = sp;
                 float t0;
