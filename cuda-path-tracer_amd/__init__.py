@@ -74,6 +74,7 @@ _sig("cpt_tracer_set_max_depth", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_channel", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_integrator", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_traversal", C.c_int, [_vp, C.c_int])
+_sig("cpt_tracer_set_node_records", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_wavefront_tail", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_set_profile_build", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_build_buffers", C.c_int, [_vp])
@@ -117,6 +118,7 @@ _sig("cpt_multi_destroy", None, [_vp])
 _sig("cpt_multi_set_max_depth", C.c_int, [_vp, C.c_int])
 _sig("cpt_multi_set_integrator", C.c_int, [_vp, C.c_int])
 _sig("cpt_multi_set_traversal", C.c_int, [_vp, C.c_int])
+_sig("cpt_multi_set_node_records", C.c_int, [_vp, C.c_int])
 _sig("cpt_multi_set_samples_per_launch", C.c_int, [_vp, C.c_uint32])
 _sig("cpt_multi_build_buffers", C.c_int, [_vp])
 _sig("cpt_multi_render", C.c_int, [_vp, C.c_uint32, _vp])
@@ -347,6 +349,10 @@ class Tracer:
         """0 exact (the reference's order and arithmetic, bit-exact), 1 fast (ordered traversal)."""
         check(lib.cpt_tracer_set_traversal(self.h, mode))
 
+    def set_node_records(self, mode):
+        """-1 two-level node records from 65,536 triangles on (default), 0 never, 1 always; before build_buffers."""
+        check(lib.cpt_tracer_set_node_records(self.h, mode))
+
     def set_wavefront_tail(self, bounces):
         check(lib.cpt_tracer_set_wavefront_tail(self.h, bounces))
 
@@ -531,6 +537,9 @@ class MultiTracer:
 
     def set_traversal(self, mode):
         check(lib.cpt_multi_set_traversal(self.h, mode))
+
+    def set_node_records(self, mode):
+        check(lib.cpt_multi_set_node_records(self.h, mode))
 
     def set_samples_per_launch(self, samples):
         check(lib.cpt_multi_set_samples_per_launch(self.h, samples))

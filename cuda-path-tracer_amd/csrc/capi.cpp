@@ -397,6 +397,12 @@ int cpt_tracer_set_traversal(cpt_tracer *t, int mode) {
     t->tracer->SetTraversal(mode);
     return CPT_OK;
 }
+int cpt_tracer_set_node_records(cpt_tracer *t, int mode) {
+    TRACER_OR_FAIL(t);
+    if (mode < -1 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_node_records: -1 (by scene size), 0 (binary only) or 1 (two-level too)");
+    t->tracer->SetNodeRecords(mode);
+    return CPT_OK;
+}
 int cpt_tracer_set_wavefront_tail(cpt_tracer *t, int bounces) { TRACER_OR_FAIL(t); t->tracer->SetWavefrontTail(bounces); return CPT_OK; }
 int cpt_tracer_set_profile_build(cpt_tracer *t, int on) { TRACER_OR_FAIL(t); t->tracer->SetProfileBuild(on != 0); return CPT_OK; }
 int cpt_tracer_build_buffers(cpt_tracer *t) {
@@ -623,6 +629,12 @@ int cpt_multi_set_traversal(cpt_multi *m, int mode) {
     MULTI_OR_FAIL(m);
     if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_multi_set_traversal: 0 (exact) or 1 (fast)");
     m->tracer->SetTraversal(mode);
+    return CPT_OK;
+}
+int cpt_multi_set_node_records(cpt_multi *m, int mode) {
+    MULTI_OR_FAIL(m);
+    if (mode < -1 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_multi_set_node_records: -1 (by scene size), 0 (binary only) or 1 (two-level too)");
+    m->tracer->SetNodeRecords(mode);
     return CPT_OK;
 }
 int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples) {

@@ -53,6 +53,7 @@ struct MeshDev {
     AccelRoot root;
     uint32_t num_triangles;
     uint32_t pad;
+    const PackedNode *wide;     // two records per internal node (see k_pack_wide), or null
 };
 
 struct InstanceDev {
@@ -129,6 +130,8 @@ struct SceneDev {
     Counters *counters;         // kCounterSlots slots; may be null
     int fast_traversal;         // 0: the reference's traversal order and arithmetic (bit-exact results); 1: ordered traversal (trace.h)
     int large_scene;            // the BVH is far larger than the caches next to the CUs: batch queries use the kernel builds for such scenes
+    const PackedNode *top_wide; // the top level in two-level records, or null
+    int wide_nodes;             // every BVH of the scene has its two-level records
 };
 
 struct RenderParams {

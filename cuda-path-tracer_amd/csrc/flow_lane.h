@@ -42,12 +42,13 @@ struct Flow {
         return q;
     }
     // Begins the ray (ow, dw) of reach `reach`; afterwards walking() is false if it missed everything at once.
+    template <bool WIDE = false>
     __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float reach, const Prepared &q, LaneCounters &cnt, bool count = true) {
         if (count) cnt.rays++;
         tmax = reach;
         sp = 0; sp_base = 0;
         in_blas = false; found = false;
-        nodes = sc.top_nodes;
+        nodes = WIDE ? sc.top_wide : sc.top_nodes;
         f.o = ow; f.d = dw; f.r = q.r; f.fast = q.fast;
         world_r = q.r;
         world_fast = q.fast;
@@ -58,9 +59,10 @@ struct Flow {
     // enters or leaves an instance); any: it is a shadow ray (AccelTop::Occlude, accel.cuh:152-173) and not
     // an extension ray (AccelTop::Intersect, accel.cuh:124-150).  A lane whose ray ends is left with
     // walking() false.  Returns false, in every lane, when no lane of the wave had a step to take.
-    template <class Stack, class World>
+    template <class Stack, class World, bool WIDE = false>
     __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, World world, bool any) {
         constexpr bool FAST = Stack::kFast;        // the ordered traversal of trace.h (Traversal), same rules
+        static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -71,7 +73,25 @@ struct Flow {
         const unsigned long long stat_t0 = clock64();
 #endif
         if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
-            if (is_node) {
+            if constexpr (WIDE) {
+                if (is_node) {                          // two levels per record, as in Traversal::vote_step
+                    GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
+                    const float4 a0 = load_f4(q, 0), a1 = load_f4(q, 1), a2 = load_f4(q, 2), a3 = load_f4(q, 3);
+                    const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6), b3 = load_f4(q, 7);
+                    cnt.nodes++;
+                    const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(b3.x), r3 = __float_as_uint(b3.y);
+                    float t0, t1, t2, t3;
+                    const bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, kRayTMin, t0) && t0 < tmax;
+                    const bool h1 = r1 != kNoNode && slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, kRayTMin, t1) && t1 < tmax;
+                    const bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, kRayTMin, t2) && t2 < tmax;
+                    const bool h3 = r3 != kNoNode && slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, kRayTMin, t3) && t3 < tmax;
+                    if (h3 && (h0 || h1 || h2)) { st.push(sp, r3, t3); sp++; }
+                    if (h2 && (h0 || h1)) { st.push(sp, r2, t2); sp++; }
+                    if (h1 && h0) { st.push(sp, r1, t1); sp++; }
+                    if (h0 || h1 || h2 || h3) cur = h0 ? r0 : h1 ? r1 : h2 ? r2 : r3;
+                    else need_pop = true;
+                }
+            } else if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
                 cnt.nodes++;
@@ -133,7 +153,7 @@ struct Flow {
                 inst_id = cur & ~kLeafBit;
                 const InstanceDev &in = sc.instances[inst_id];
                 const MeshDev &m = sc.meshes[in.mesh];
-                nodes = m.nodes;
+                nodes = WIDE ? m.wide : m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
                 if constexpr (FAST) inst_pos = in.tlas_position;
@@ -154,7 +174,7 @@ struct Flow {
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
-                if (in_blas && sp == sp_base) { in_blas = false; world(f.o, f.d); f.r = world_r; f.fast = world_fast; nodes = sc.top_nodes; }
+                if (in_blas && sp == sp_base) { in_blas = false; world(f.o, f.d); f.r = world_r; f.fast = world_fast; nodes = WIDE ? sc.top_wide : sc.top_nodes; }
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);

@@ -233,6 +233,7 @@ void MultiPathTracer::BuildBuffers() {
         t.SetTraversal(traversal_);
         t.SetSamplesPerLaunch(samples_per_launch_);
         t.SetWavefrontTail(wavefront_tail_);
+        t.SetNodeRecords(node_records_);
         t.BuildBuffers();
     });
     built_ = true;

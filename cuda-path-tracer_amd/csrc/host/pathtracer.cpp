@@ -17,6 +17,8 @@ inline void rc_check(int rc, const char *what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
 }
 
+// about 7 MB of node and triangle records: beyond that the BVH no longer lives in the caches next to the CUs
+constexpr size_t kLargeSceneTriangles = 65536;
 }  // namespace
 
 PathTracer::PathTracer(Scene &scene, Film &film) : scene_(scene), film_(film) {}
@@ -35,11 +37,10 @@ void PathTracer::BuildBuffers() {
     has_camera_ = CameraFromScene(scene_dev_.camera);
 
     BuildInstancesAndLights();
-    // about 7 MB of node and triangle records: beyond that the BVH no longer lives in the caches next to the CUs
     size_t triangles = 0;
     scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { triangles += mesh.GetMesh()->IndicesCount() / 3; });
     scene_triangles_ = triangles;
-    const bool dense = triangles >= 65536;
+    const bool dense = triangles >= kLargeSceneTriangles;
     if (dense != wf_dense_) { wf_dense_ = dense; wf_.capacity = 0; }      // the resident workgroup count is looked up again
     scene_dev_.large_scene = dense ? 1 : 0;
     CPT_HIP(hipStreamSynchronize(stream_));
@@ -168,6 +169,9 @@ void PathTracer::BuildAccel() {
     uint32_t num_instances = (uint32_t)instance_mesh_.size();
     if (num_instances == 0) return;
 
+    size_t scene_triangles = 0;
+    scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { scene_triangles += mesh.GetMesh()->IndicesCount() / 3; });
+    const bool wide = node_records_ > 0 || (node_records_ < 0 && scene_triangles >= kLargeSceneTriangles);
     // mesh descriptor table; the pack kernels fill in each root afterwards
     std::vector<cpt::MeshDev> mesh_table(meshes_.size());
     for (size_t i = 0; i < meshes_.size(); i++) {
@@ -181,6 +185,10 @@ void PathTracer::BuildAccel() {
         d.normals = mb.normals.TypedGpuData<V3>();
         d.texcoords = mb.texcoords.TypedGpuData<cpt::V2>();
         d.num_triangles = mb.num_triangles;
+        if (wide) {
+            mb.wide_nodes.Allocate(sizeof(cpt::PackedNode) * 2 * (mb.num_triangles > 1 ? mb.num_triangles - 1 : 1));
+            d.wide = mb.wide_nodes.TypedGpuData<cpt::PackedNode>();
+        }
     }
     mesh_table_.Allocate(sizeof(cpt::MeshDev) * mesh_table.size(), mesh_table.data(), stream_);
     for (size_t i = 0; i < meshes_.size(); i++) {
@@ -204,6 +212,8 @@ void PathTracer::BuildAccel() {
         rc_check(cpt::lbvh_pack(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.tris.TypedGpuData<cpt::TriRecord>(), root,
                                 mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles,
                                 mb.indices.TypedGpuData<uint32_t>(), mb.positions.TypedGpuData<V3>(), stream_), "pack bottom level");
+        if (wide) rc_check(cpt::lbvh_pack_wide(mb.wide_nodes.TypedGpuData<cpt::PackedNode>(), mb.nodes.TypedGpuData<cpt::AccelNode>(),
+                                               mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles, false, stream_), "pack bottom level, two-level records");
     }
 
     // top level (pathtracer.cpp:120-154)
@@ -229,6 +239,15 @@ void PathTracer::BuildAccel() {
                             top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), num_instances, nullptr, nullptr, stream_),
              "pack top level");
 
+    scene_dev_.top_wide = nullptr;
+    scene_dev_.wide_nodes = 0;
+    if (wide) {
+        top_wide_.Allocate(sizeof(cpt::PackedNode) * 2 * (num_instances > 1 ? num_instances - 1 : 1));
+        rc_check(cpt::lbvh_pack_wide(top_wide_.TypedGpuData<cpt::PackedNode>(), top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(),
+                                     num_instances, true, stream_), "pack top level, two-level records");
+        scene_dev_.top_wide = top_wide_.TypedGpuData<cpt::PackedNode>();
+        scene_dev_.wide_nodes = 1;
+    }
     scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
     scene_dev_.top_root = top_root_.TypedGpuData<cpt::AccelRoot>();
     scene_dev_.meshes = mesh_table_.TypedGpuData<cpt::MeshDev>();

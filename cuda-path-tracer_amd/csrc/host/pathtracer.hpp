@@ -43,6 +43,12 @@ public:
     // integrators 4 and 5 (and 3, which picks one of them); integrators 0, 1 and 2 always run exact.
     void SetTraversal(int mode) { scene_dev_.fast_traversal = mode ? 1 : 0; }
     int Traversal() const { return scene_dev_.fast_traversal; }
+    // Two-level node records next to the binary ones (128 bytes per internal node: the node's grandchildren in the order
+    // the reference reaches them), walked by the exact traversal of the kernels for large scenes (batch queries,
+    // integrators 2 and 4): half as many dependent record fetches per ray, the same leaves in the same order.
+    // -1: from 65,536 triangles on (default); 0: never; 1: always.  Takes effect at the next BuildBuffers.
+    void SetNodeRecords(int mode) { node_records_ = mode; }
+    bool HasTwoLevelRecords() const { return scene_dev_.wide_nodes != 0; }
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
     // 2: wavefront (ray queues in HBM, one kernel sequence per bounce); 4: persistent megakernel that keeps traversal
     // state across shading; 5: persistent megakernel whose finished lanes walk pooled shadow rays; 3: 4 or 5 by the
@@ -100,6 +106,7 @@ private:
         cpt::HipBuffer positions, normals, texcoords, indices;
         cpt::HipBuffer nodes, bboxes, keys;          // reference-layout build output
         cpt::HipBuffer packed_nodes, tris;           // traversal records
+        cpt::HipBuffer wide_nodes;                   // two-level records, when built
         uint32_t num_triangles = 0;
     };
 
@@ -143,7 +150,8 @@ private:
     std::unordered_map<const Mesh *, uint32_t> mesh_index_;
     std::vector<uint32_t> instance_mesh_;            // instance -> mesh table index
     cpt::HipBuffer leaf_scratch_;
-    cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_;
+    cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_, top_wide_;
+    int node_records_ = -1;
     cpt::HipBuffer mesh_table_, instance_table_, material_table_, light_table_, counters_;
     cpt::HipBuffer texel_pool_, texture_table_, srgb_table_;
     uint32_t num_lights_ = 0;

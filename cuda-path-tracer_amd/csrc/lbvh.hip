@@ -931,6 +931,38 @@ __global__ void __launch_bounds__(kBlock) k_pack_nodes(PackedNode *__restrict__ 
     o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
 }
 
+// Two levels of the tree per record: internal node i becomes two 64-byte halves in the layout of PackedNode, the first
+// for its right child, the second for its left child.  A half holds the child itself when the child is a leaf (second
+// slot empty: reference kNoChild), otherwise the child's two children, right one first.  The four slots are in the
+// order the reference's traversal (right child first, accel.cuh:84-91) reaches them.
+constexpr uint32_t kNoChild = 0xffffffffu;
+__global__ void __launch_bounds__(kBlock) k_pack_wide(PackedNode *__restrict__ out, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes,
+                                                       uint32_t n, int top_level) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (n < 2 || i >= n - 1) return;
+    const AccelNode nd = nodes[i];
+    auto half = [&](uint32_t c, float4 *o) {
+        Bbox a, b;
+        uint32_t ra, rb = kNoChild;
+        b.pmin = V4{0.0f, 0.0f, 0.0f, 0.0f}; b.pmax = b.pmin;
+        if (c >= n - 1) {
+            a = bboxes[c];
+            ra = child_ref(c, nodes, n, top_level);
+        } else {
+            const AccelNode cn = nodes[c];
+            a = bboxes[cn.rc]; ra = child_ref(cn.rc, nodes, n, top_level);
+            b = bboxes[cn.lc_or_id]; rb = child_ref(cn.lc_or_id, nodes, n, top_level);
+        }
+        o[0] = make_float4(a.pmin.x, a.pmin.y, a.pmin.z, a.pmax.x);
+        o[1] = make_float4(a.pmax.y, a.pmax.z, b.pmin.x, b.pmin.y);
+        o[2] = make_float4(b.pmin.z, b.pmax.x, b.pmax.y, b.pmax.z);
+        o[3] = make_float4(__uint_as_float(ra), __uint_as_float(rb), 0.0f, 0.0f);
+    };
+    float4 *o = reinterpret_cast<float4 *>(out + 2 * (size_t)i);
+    half(nd.rc, o);
+    half(nd.lc_or_id, o + 4);
+}
+
 __global__ void __launch_bounds__(kBlock) k_pack_tris(TriRecord *__restrict__ out, const AccelNode *__restrict__ nodes, const uint32_t *__restrict__ indices,
                                                        const V3 *__restrict__ positions, uint32_t n) {
     uint32_t s = blockIdx.x * kBlock + threadIdx.x;
@@ -1160,6 +1192,12 @@ int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const
     HIP_OK(hipMemsetAsync(root, 0, sizeof(AccelRoot), stream));
     hipLaunchKernelGGL(k_pack_nodes, dim3(cdiv(n > 1 ? n - 1 : 1, kBlock)), dim3(kBlock), 0, stream, out_nodes, nodes, bboxes, n, top_level, root);
     if (!top_level) hipLaunchKernelGGL(k_pack_tris, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, out_tris, nodes, indices, positions, n);
+    return (int)hipGetLastError();
+}
+
+int lbvh_pack_wide(PackedNode *out_wide, const AccelNode *nodes, const Bbox *bboxes, uint32_t n, bool top_level, hipStream_t stream) {
+    if (n < 2) return 0;
+    hipLaunchKernelGGL(k_pack_wide, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, out_wide, nodes, bboxes, n, top_level ? 1 : 0);
     return (int)hipGetLastError();
 }
 

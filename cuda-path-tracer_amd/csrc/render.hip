@@ -179,7 +179,7 @@ constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spille
 #endif
 constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
-template <bool MAPS, bool FAST>
+template <bool MAPS, bool FAST, bool WIDE = false>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
                     q.r = v3(s_next[threadIdx.x], s_next[kTraceBlock + threadIdx.x], s_next[2 * kTraceBlock + threadIdx.x]);
                     const uint32_t flags = __float_as_uint(s_next[3 * kTraceBlock + threadIdx.x]);
                     q.fast = flags & 1u; q.enters = flags & 2u;
-                    t.begin(sc, s.l.ro, s.l.rd, kRayTMax, q, cnt);
+                    t.template begin<WIDE>(sc, s.l.ro, s.l.rd, kRayTMax, q, cnt);
                 }
             }
             if (!s.has_shadow && !t.walking()) { s.ext_traced = s.has_ext; s.has_ext = false; }
@@ -255,9 +255,9 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
                     s_next[threadIdx.x] = ext.r.x; s_next[kTraceBlock + threadIdx.x] = ext.r.y; s_next[2 * kTraceBlock + threadIdx.x] = ext.r.z;
                     s_next[3 * kTraceBlock + threadIdx.x] = __uint_as_float((ext.fast ? 1u : 0u) | (ext.enters ? 2u : 0u));
                 }
-                t.begin(sc, s.l.ro, s.shadow_dir, s.shadow_tmax, Flow::prepare<FAST>(sc, s.l.ro, s.shadow_dir, s.shadow_tmax), cnt);
+                t.template begin<WIDE>(sc, s.l.ro, s.shadow_dir, s.shadow_tmax, Flow::prepare<FAST>(sc, s.l.ro, s.shadow_dir, s.shadow_tmax), cnt);
             } else {
-                t.begin(sc, s.l.ro, s.l.rd, kRayTMax, ext, cnt);
+                t.template begin<WIDE>(sc, s.l.ro, s.l.rd, kRayTMax, ext, cnt);
             }
             if (!t.walking()) ray_ended();
         }
@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
         // code into nearly every trip for one or two lanes, so it runs every sixteenth trip and when nothing moves.
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = s.has_shadow;
-            const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) { ow = s.l.ro; dw = shadow ? s.shadow_dir : s.l.rd; }, shadow);
+            auto world = [&](V3 &ow, V3 &dw) { ow = s.l.ro; dw = shadow ? s.shadow_dir : s.l.rd; };
+            const bool moved = t.template step<decltype(st), decltype(world), WIDE>(sc, st, cnt, world, shadow);
             if (moved && (trip & 15u) != 15u) continue;
             if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
@@ -436,13 +437,17 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
 // The batch query kernels hold one ray and no path state: few registers, so more waves per SIMD when
 // the LDS stack is shortened to match (deeper entries go to private memory).
 constexpr int kQueryWaves = 8;
+#ifndef WIDE_WAVES
+#define WIDE_WAVES 5
+#endif
+constexpr int kWideQueryWaves = WIDE_WAVES;
 constexpr int kQueryLdsEntries = 8;
 // batches are often coherent camera rays, which lose with the bounce loops' weight of 4 (heightfield 10M: 2.59 Grays/s
 // with 1 or 2, 2.46 with 4) while diverging ones gain (soup 1M: 0.67 with 1, 0.75 with 2, 0.81 with 4)
 constexpr int kQueryLeafWeightLargeScene = 2;
 
-template <bool LARGE, bool FAST>
-__global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
+template <bool LARGE, bool FAST, bool WIDE = false>
+__global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -455,7 +460,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        bool ok = trace<false>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
+        bool ok = trace<false, decltype(st), WIDE>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
         inst_out[i] = ok ? hit.inst : 0xffffffffu;
         prim_out[i] = ok ? hit.prim : 0xffffffffu;
         if (t_out) t_out[i] = tmax;
@@ -464,8 +469,8 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_first_hit(SceneDev
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
-template <bool LARGE, bool FAST>
-__global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
+template <bool LARGE, bool FAST, bool WIDE = false>
+__global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(kTraceBlock, kQueryWaves) k_occlude(SceneDev s
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        out[i] = trace<true>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
+        out[i] = trace<true, decltype(st), WIDE>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
     }
     flush_counters(sc, cnt, 0u, s_cnt);
 }
@@ -623,6 +628,11 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
         return (int)hipGetLastError();
     }
     if (variant == 1) {
+        if (sc.wide_nodes && !fast) {
+            if (sc.textures) hipLaunchKernelGGL((k_render_flow<true, false, true>), grid, block, 0, stream, sc, p, queue, parity);
+            else hipLaunchKernelGGL((k_render_flow<false, false, true>), grid, block, 0, stream, sc, p, queue, parity);
+            return (int)hipGetLastError();
+        }
         if (sc.textures) {
             if (fast) hipLaunchKernelGGL((k_render_flow<true, true>), grid, block, 0, stream, sc, p, queue, parity);
             else hipLaunchKernelGGL((k_render_flow<true, false>), grid, block, 0, stream, sc, p, queue, parity);
@@ -671,6 +681,10 @@ int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
     const dim3 grid((uint32_t)blocks), block(kTraceBlock);
     const unsigned long long count = n;
+    if (sc.wide_nodes && !sc.fast_traversal) {
+        hipLaunchKernelGGL((k_first_hit<true, false, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv);
+        return (int)hipGetLastError();
+    }
     switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((k_first_hit<false, false>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
         case 1: hipLaunchKernelGGL((k_first_hit<false, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
@@ -686,6 +700,10 @@ int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *o
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
     const dim3 grid((uint32_t)blocks), block(kTraceBlock);
     const unsigned long long count = n;
+    if (sc.wide_nodes && !sc.fast_traversal) {
+        hipLaunchKernelGGL((k_occlude<true, false, true>), grid, block, 0, stream, sc, rays, count, out);
+        return (int)hipGetLastError();
+    }
     switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((k_occlude<false, false>), grid, block, 0, stream, sc, rays, count, out); break;
         case 1: hipLaunchKernelGGL((k_occlude<false, true>), grid, block, 0, stream, sc, rays, count, out); break;

@@ -305,14 +305,14 @@ struct Traversal {
     Hit hit;
 
     // tests the top-level root box; afterwards live() tells whether there is anything to walk
-    template <bool FAST = false>
+    template <bool FAST = false, bool WIDE = false>
     __device__ inline void begin(const SceneDev &sc, V3 ow, V3 dw, float tmin_, float tmax_, LaneCounters &cnt) {
         cnt.rays++;
         cur = kNoNode;
         sp = 0; sp_base = 0;
         in_blas = false; found = false;
         tmin = tmin_; tmax = tmax_;
-        nodes = sc.top_nodes;
+        nodes = WIDE ? sc.top_wide : sc.top_nodes;
         const AccelRoot troot = *sc.top_root;
         world.set_for<FAST>(ow, dw, troot.flags == 0);
         f = world;
@@ -322,9 +322,10 @@ struct Traversal {
     __device__ inline bool live() const { return cur != kNoNode; }
 
     // returns false when no lane of the wave that called it has work left
-    template <bool ANY, class Stack>
+    template <bool ANY, class Stack, bool WIDE = false>
     __device__ inline bool vote_step(const SceneDev &sc, Stack &st, LaneCounters &cnt) {
         constexpr bool FAST = Stack::kFast;
+        static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -334,7 +335,29 @@ struct Traversal {
         const int cn = lanes_in(mn), ct = lanes_in(mt), ci = lanes_in(mi);
         bool need_pop = false;
         if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
-            if (is_node) {
+            if constexpr (WIDE) {
+                // Two levels per record, slots in the order the reference reaches them (right child first).  A slot
+                // is walked iff its own box is hit within the reach: its parent's box contains it, and every operation
+                // of the slab test is monotonic in the box coordinates, so the parent's test (which the reference
+                // makes first) cannot fail where the slot's succeeds, nor can the parent's entry distance be larger.
+                if (is_node) {
+                    GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
+                    const float4 a0 = load_f4(q, 0), a1 = load_f4(q, 1), a2 = load_f4(q, 2), a3 = load_f4(q, 3);
+                    const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6), b3 = load_f4(q, 7);
+                    cnt.nodes++;
+                    const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(b3.x), r3 = __float_as_uint(b3.y);
+                    float t0, t1, t2, t3;
+                    const bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, tmin, t0) && t0 < tmax;
+                    const bool h1 = r1 != kNoNode && slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t1) && t1 < tmax;
+                    const bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t2) && t2 < tmax;
+                    const bool h3 = r3 != kNoNode && slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, tmin, t3) && t3 < tmax;
+                    if (h3 && (h0 || h1 || h2)) { st.push(sp, r3, t3); sp++; }
+                    if (h2 && (h0 || h1)) { st.push(sp, r2, t2); sp++; }
+                    if (h1 && h0) { st.push(sp, r1, t1); sp++; }
+                    if (h0 || h1 || h2 || h3) cur = h0 ? r0 : h1 ? r1 : h2 ? r2 : r3;
+                    else need_pop = true;
+                }
+            } else if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);
                 float4 q0 = load_f4(q, 0), q1 = load_f4(q, 1), q2 = load_f4(q, 2), q3 = load_f4(q, 3);
                 cnt.nodes++;
@@ -394,7 +417,7 @@ struct Traversal {
                 inst_id = cur & ~kLeafBit;
                 const InstanceDev &in = sc.instances[inst_id];
                 const MeshDev &m = sc.meshes[in.mesh];
-                nodes = m.nodes;
+                nodes = WIDE ? m.wide : m.nodes;
                 tris = m.tris;
                 AccelRoot r = m.root;
                 if constexpr (FAST) inst_pos = in.tlas_position;
@@ -409,7 +432,7 @@ struct Traversal {
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
-                if (in_blas && sp == sp_base) { in_blas = false; f = world; nodes = sc.top_nodes; }
+                if (in_blas && sp == sp_base) { in_blas = false; f = world; nodes = WIDE ? sc.top_wide : sc.top_nodes; }
                 if (sp == 0) break;
                 --sp;
                 uint2 e = st.at(sp);
@@ -423,11 +446,11 @@ struct Traversal {
 // One ray per lane, all lanes of the wave that reach the call together (`active` = false for
 // lanes with nothing to trace); returns when every lane's ray is finished.  tmax is updated to
 // the hit distance on closest hits.
-template <bool ANY, class Stack>
+template <bool ANY, class Stack, bool WIDE = false>
 __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, Stack &st, LaneCounters &cnt) {
     Traversal t;
-    if (active) t.begin<Stack::kFast>(sc, ow, dw, tmin, tmax, cnt);
-    while (t.vote_step<ANY>(sc, st, cnt)) {}
+    if (active) t.begin<Stack::kFast, WIDE>(sc, ow, dw, tmin, tmax, cnt);
+    while (t.vote_step<ANY, Stack, WIDE>(sc, st, cnt)) {}
     if (!ANY && t.found) { hit = t.hit; tmax = t.tmax; }
     return t.found;
 }

@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
 // ray, result to wb.hit.  ANY = true: the path's shadow ray; an unoccluded ray adds the pending
 // light contribution to the path's colour, and a path that was only waiting for this ray is
 // written to the film.
-template <bool ANY, bool DENSE>
-__global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
+template <bool ANY, bool DENSE, bool WIDE = false>
+__global__ void __launch_bounds__(kTraceBlock, WIDE ? 5 : QueueTraceShape<DENSE>::kWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[QueueTraceShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
@@ -87,10 +87,10 @@ __global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k
                     path = entry;
                     if (ANY) {
                         float4 o = wb.sh_o[path], d = wb.sh_d[path];
-                        t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, o.w, cnt);
+                        t.template begin<false, WIDE>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, o.w, cnt);
                     } else {
                         float4 o = wb.ray_o[path], d = wb.ray_d[path];
-                        t.begin(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, kRayTMax, cnt);
+                        t.template begin<false, WIDE>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), kRayTMin, kRayTMax, cnt);
                     }
                     have = true;
                 }
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(kTraceBlock, QueueTraceShape<DENSE>::kWaves) k
             }
         }
         if (__ballot(have) == 0ull) break;
-        t.vote_step<ANY>(sc, st, cnt);
+        t.template vote_step<ANY, decltype(st), WIDE>(sc, st, cnt);
         if (have && !t.live()) {
             if (ANY) {
                 float4 c = wb.col[path];
@@ -291,8 +291,9 @@ static int resident_blocks_of(const void *const *kernels, int count, int device)
 
 int wavefront_resident_blocks(int device, bool dense) {
     const void *sparse_kernels[2] = {(const void *)k_wf_trace<false, false>, (const void *)k_wf_trace<true, false>};
-    const void *dense_kernels[2] = {(const void *)k_wf_trace<false, true>, (const void *)k_wf_trace<true, true>};
-    return resident_blocks_of(dense ? dense_kernels : sparse_kernels, 2, device);
+    const void *dense_kernels[4] = {(const void *)k_wf_trace<false, true>, (const void *)k_wf_trace<true, true>, (const void *)k_wf_trace<false, true, true>,
+                                    (const void *)k_wf_trace<true, true, true>};
+    return dense ? resident_blocks_of(dense_kernels, 4, device) : resident_blocks_of(sparse_kernels, 2, device);
 }
 
 int wavefront_finish_resident_blocks(int device) {
@@ -318,11 +319,13 @@ int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontB
                      hipStream_t stream) {
     const uint32_t blocks = persistent_blocks(wb, resident_blocks);
     const uint32_t shade_blocks = (wb.segments + 3) / 4;
-    if (dense) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    if (sc.wide_nodes) hipLaunchKernelGGL((k_wf_trace<false, true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    else if (dense) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     if (sc.textures) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
     else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
-    if (dense) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    if (sc.wide_nodes) hipLaunchKernelGGL((k_wf_trace<true, true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    else if (dense) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }

@@ -158,6 +158,15 @@ int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
  * reported (the nearest; at exactly equal distance the one later in instance and sorted-leaf order).  Applies to
  * cpt_tracer_first_hit / cpt_tracer_occlude and to integrators 3, 4 and 5; integrators 0, 1 and 2 always run exact. */
 int cpt_tracer_set_traversal(cpt_tracer *t, int mode);
+/* Node records of the exact traversal (no counterpart in the reference, which walks one AccelNode and two Bbox per step,
+ * accel.cuh:68-90): next to the 64-byte binary records the build can lay down two-level records, 128 bytes per internal
+ * node holding the boxes and references of its (up to four) grandchildren in the order accel.cuh:84-91 reaches them.
+ * A ray then fetches half as many dependent records; because a child's box lies inside its parent's and every
+ * operation of BboxIntersect is monotonic in the box coordinates, testing the grandchildren directly walks exactly
+ * the leaves the reference walks, in its order: results stay bit-exact.  Used by cpt_tracer_first_hit /
+ * cpt_tracer_occlude and integrators 2 and 4 in exact traversal.  mode: -1 = from 65,536 triangles on (default),
+ * 0 = never, 1 = always; takes effect at the next cpt_tracer_build_buffers. */
+int cpt_tracer_set_node_records(cpt_tracer *t, int mode);
 /* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
  * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette
  * paths costs a kernel sequence per bounce otherwise).  Negative = never, queues to the end
@@ -274,6 +283,7 @@ void cpt_multi_destroy(cpt_multi *m);
 int cpt_multi_set_max_depth(cpt_multi *m, int max_depth);
 int cpt_multi_set_integrator(cpt_multi *m, int mode);
 int cpt_multi_set_traversal(cpt_multi *m, int mode);                          /* as cpt_tracer_set_traversal, for every shard */
+int cpt_multi_set_node_records(cpt_multi *m, int mode);                       /* as cpt_tracer_set_node_records, for every shard */
 int cpt_multi_set_samples_per_launch(cpt_multi *m, uint32_t samples);
 int cpt_multi_build_buffers(cpt_multi *m);
 int cpt_multi_render(cpt_multi *m, uint32_t total_spp, float *elapsed_ms);

@@ -197,8 +197,8 @@ def test_synthetic_scene_render(cpt):
 @pytest.mark.parametrize("kind,depth", [("heightfield", 5), ("soup", -1)])
 def test_large_scene_builds_of_the_integrators_agree(cpt, kind, depth):
     """From 65,536 triangles on the library runs the kernel builds meant for BVHs that miss the caches, and
-    mode 3 picks the persistent kernel that shades partly finished waves (4): same film and same counters as
-    the plain persistent kernel (0) and the ray queues (2), and close to the oracle."""
+    mode 3 picks the persistent kernel that shades partly finished waves (4): same film, rays, triangle tests and
+    shading steps as the plain persistent kernel (0) and the ray queues (2), and close to the oracle."""
     objs, cam = synthetic_scene(kind, 70000)
     imgs, rays = [], []
     for mode in (0, 2, 3, 4, 5):
@@ -207,10 +207,12 @@ def test_large_scene_builds_of_the_integrators_agree(cpt, kind, depth):
         tr.update(4)
         imgs.append(tr.film())
         c = tr.counters()
-        rays.append((c["rays"], c["node_visits"], c["tri_tests"], c["shades"]))
+        rays.append((c["rays"], c["tri_tests"], c["shades"], c["node_visits"]))
     for k in range(1, len(imgs)):
         assert np.array_equal(imgs[0].view(np.uint32), imgs[k].view(np.uint32)), k
-        assert rays[0] == rays[k], k
+        assert rays[0][:3] == rays[k][:3], k
+    # node records fetched: modes 0 and 5 walk the binary records, 2 and 4 (and 3, which is 4 here) the two-level ones
+    assert rays[0][3] == rays[4][3] and rays[2][3] == rays[3][3] and rays[3][3] < 0.62 * rays[0][3]
     if kind == "heightfield":
         ref, _ = OracleScene(objs, cam).render(100, 60, 1, 5, depth)
         compare(imgs[0], ref)
@@ -460,3 +462,33 @@ def test_render_entry_point_at_the_kernel_level(cpt):
         tr.render_one(None, W, H, 1)
     with pytest.raises(cpt.CptError):
         tr.render_one(out.ptr, W, H, 0)
+
+
+def test_two_level_records_give_the_same_image(cpt):
+    """Integrators 2 (wavefront) and 4 (persistent megakernel for large scenes) with and without the two-level node
+    records: the same film bit for bit, the same rays and triangle tests."""
+    objs, cam = synthetic_scene("heightfield", 120000)
+    sc = cpt.Scene()
+    for o in objs:
+        sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+    W, H = 320, 192
+    sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
+    films, work = {}, {}
+    for records in (0, 1, -1):
+        for integrator in (2, 4):
+            tr = cpt.Tracer(sc, W, H, max_depth=6)
+            tr.set_node_records(records)
+            tr.set_integrator(integrator)
+            tr.build_buffers()
+            tr.update(5)
+            films[(records, integrator)] = tr.film()
+            c = tr.counters()
+            work[(records, integrator)] = (c["rays"], c["tri_tests"], c["node_visits"])
+            assert tr.stack_overflows() == 0
+    ref = films[(0, 4)]
+    assert ref[..., :3].mean() > 1e-3
+    for key, film in films.items():
+        assert np.array_equal(film, ref), key
+        assert work[key][:2] == work[(0, 4)][:2], key
+    assert work[(1, 4)][2] < 0.62 * work[(0, 4)][2]
+    assert work[(-1, 4)] == work[(1, 4)]                     # 120,000 triangles: past the size from which they are built

@@ -11,14 +11,16 @@ from helpers import *  # noqa: F403
 pytestmark = pytest.mark.gpu
 
 
-def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5):
+def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5, node_records=-1):
     sc = cpt.Scene()
     for o in objects:
         sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
         if "trs" in o:
             sc.set_trs(sc.num_objects() - 1, *o["trs"])
     sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], width, height)
-    return sc, cpt.Tracer(sc, width, height, max_depth=max_depth).build_buffers()
+    tr = cpt.Tracer(sc, width, height, max_depth=max_depth)
+    tr.set_node_records(node_records)
+    return sc, tr.build_buffers()
 
 
 def interior_rays(n, seed, lo, hi, tmax=None):
@@ -259,3 +261,49 @@ def test_fast_traversal_against_exact(cpt, scene):
     changed = np.any(fast[..., :3] != exact[..., :3], axis=-1).mean()
     assert changed <= (0.2 if scene == "cornell" else 1e-3), changed
     assert np.allclose(fast[..., :3].mean(axis=(0, 1)), exact[..., :3].mean(axis=(0, 1)), rtol=0.02)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "moved", "heightfield", "soup", "two", "one"])
+def test_two_level_records_walk_the_same_leaves(cpt, scene):
+    """The two-level node records (the grandchildren of a node in one 128-byte record, tested without their parents'
+    boxes) against the binary records and against the oracle: first hits, any-hit answers and the number of triangle
+    tests are the same, bit for bit, on camera rays, rays from inside the scene (some parallel to an axis, with
+    zeros of both signs in the direction), rays that start on box planes and short rays; only the number of node
+    records fetched changes (about half)."""
+    if scene in ("cornell", "moved"):
+        objs, cam = (cornell if scene == "cornell" else cornell_moved)(glass=True)
+        lo, hi = np.float32([-1, 0, -1]), np.float32([1, 2, 1])
+    else:
+        objs, cam = synthetic_scene("soup" if scene in ("two", "one") else scene, {"two": 2, "one": 1}.get(scene, 150000))
+        lo, hi = np.float32([0, -0.2, 0]), np.float32([1, 1.2, 1])
+    osc = OracleScene(objs, cam)
+    _, binary = gpu_scene(cpt, objs, cam, node_records=0)
+    _, wide = gpu_scene(cpt, objs, cam, node_records=1)
+    rays = np.concatenate([osc.camera_rays(256, 256, 2), interior_rays(150000, 51, lo, hi)])
+    on_planes = interior_rays(60000, 52, lo, hi)
+    on_planes[:20000, 1] = lo[1]
+    on_planes[20000:40000, 0] = hi[0]
+    on_planes[40000:, 7] = 0.3
+    rays = np.concatenate([rays, on_planes])
+    axis = interior_rays(30000, 53, lo, hi)                   # parallel to an axis: two zero components of either sign
+    for k in range(len(axis)):
+        d = np.zeros(3, np.float32) * (-1.0 if k & 8 else 1.0)
+        d[k % 3] = 1.0 if k & 4 else -1.0
+        axis[k, 4:7] = d
+    rays = np.concatenate([rays, axis])
+    binary.reset_counters()
+    b = binary.first_hit(rays)
+    wide.reset_counters()
+    w = wide.first_hit(rays)
+    for x, y in zip(b, w):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    cb, cw = binary.counters(), wide.counters()
+    assert cb["tri_tests"] == cw["tri_tests"] and cb["rays"] == cw["rays"]
+    if scene not in ("two", "one"):
+        assert cw["node_visits"] < 0.62 * cb["node_visits"]
+    assert wide.stack_overflows() == 0
+    assert_same_hits(wide, osc, rays[:200000])
+    short = rays.copy()
+    short[:, 7] = 0.45
+    assert np.array_equal(binary.occlude(short), wide.occlude(short))
+    assert np.array_equal(wide.occlude(short[:100000]), osc.occlude(short[:100000]))
