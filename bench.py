@@ -54,15 +54,20 @@ INTEGRATOR_NAME = {0: "persistent megakernel (lane regeneration)", 1: "megakerne
 COUNTER_KEYS = ("rays", "node_visits", "tri_tests", "paths", "shades")
 
 
-def traversal_bytes(c):
-    """Per ray 32 B in + 16 B hit out, 64 B per node record visited, 48 B per triangle record tested."""
-    return 48 * c["rays"] + 64 * c["node_visits"] + 48 * c["tri_tests"]
+def node_record_bytes(exact):
+    """The exact traversal walks two-level records of 128 B, the ordered one binary records of 64 B."""
+    return 128 if exact else 64
 
 
-def bounce_bytes(c, pixel_samples):
+def traversal_bytes(c, node_bytes):
+    """Per ray 32 B in + 16 B hit out, node_bytes per node record visited, 48 B per triangle record tested."""
+    return 48 * c["rays"] + node_bytes * c["node_visits"] + 48 * c["tri_tests"]
+
+
+def bounce_bytes(c, pixel_samples, node_bytes):
     """Traversal bytes + per shaded hit 3 x (12 + 12 + 8) B of vertex attributes and 112 B of material + 16 B read and
     16 B written per pixel and sample for the accumulation buffer."""
-    return traversal_bytes(c) + (96 + 112) * c["shades"] + 32 * pixel_samples
+    return traversal_bytes(c, node_bytes) + (96 + 112) * c["shades"] + 32 * pixel_samples
 
 
 def measured_counters(key):
@@ -215,7 +220,7 @@ def primary_ray_block(cpt, tracer, W, H, label):
         hits[tag] = (d_inst.to_host(), d_prim.to_host(), d_t.to_host())
         block = {"mrays_per_s": round(n / ms / 1e3, 1), "ms": round(ms, 4), "node_records_per_ray": round(c["node_visits"] / c["rays"], 2),
                  "triangles_per_ray": round(c["tri_tests"] / c["rays"], 2),
-                 "roofline": roofline_block("k_first_hit", traversal_bytes(c) / reps, ms, 1, measured_counters(f"k_first_hit/{label}/{tag}"))}
+                 "roofline": roofline_block("k_first_hit", traversal_bytes(c, node_record_bytes(mode == 0)) / reps, ms, 1, measured_counters(f"k_first_hit/{label}/{tag}"))}
         out[tag] = block
     e, f = hits["exact"], hits["fast"]
     out["fast_vs_exact"] = {"id_mismatches": int(((e[0] != f[0]) | (e[1] != f[1])).sum()), "fast_farther": int((f[2] > e[2]).sum()),
@@ -415,7 +420,7 @@ def main():
         launches = -(-own // per_launch)
         avg_ms = kernel_ms / launches
         samples_in_launch = own / launches                               # what an average timed launch really held
-        alg_bytes = bounce_bytes(counters, W * H * own) / launches
+        alg_bytes = bounce_bytes(counters, W * H * own, node_record_bytes(args.traversal == "exact")) / launches
         m = measured_counters(f"{kernel_name}/{args.workload}/{args.traversal}") if (W, H) == (1024, 1024) or args.workload != "cornell-box-glass" else None
         roof = roofline_block(kernel_name, alg_bytes, avg_ms, samples_in_launch, m)
         roof["launches"] = launches
@@ -475,7 +480,7 @@ def main():
                     kname = KERNEL_OF[mode]
                     launches = max(1, -(-count // 32)) if mode == 4 else 1            # rank 0's own launches against its own bytes
                     m = measured_counters(f"{kname}/heightfield-10m/{'fast' if trav else 'exact'}") if (depth == 5 and mode == 4) else None
-                    v["roofline"] = roofline_block(kname, bounce_bytes(c_own, w * h * count) / launches, ms_dev / launches, count / launches, m)
+                    v["roofline"] = roofline_block(kname, bounce_bytes(c_own, w * h * count, node_record_bytes(trav == 0)) / launches, ms_dev / launches, count / launches, m)
                     block[name] = v
             if rank == 0:
                 result["scene_10m"] = block

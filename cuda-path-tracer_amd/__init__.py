@@ -350,7 +350,7 @@ class Tracer:
         check(lib.cpt_tracer_set_traversal(self.h, mode))
 
     def set_node_records(self, mode):
-        """-1 two-level node records from 65,536 triangles on (default), 0 never, 1 always; before build_buffers."""
+        """1: two-level node records are built and walked by the exact traversal (default); 0: binary records only.  Before build_buffers."""
         check(lib.cpt_tracer_set_node_records(self.h, mode))
 
     def set_wavefront_tail(self, bounces):

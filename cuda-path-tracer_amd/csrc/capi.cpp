@@ -399,7 +399,7 @@ int cpt_tracer_set_traversal(cpt_tracer *t, int mode) {
 }
 int cpt_tracer_set_node_records(cpt_tracer *t, int mode) {
     TRACER_OR_FAIL(t);
-    if (mode < -1 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_node_records: -1 (by scene size), 0 (binary only) or 1 (two-level too)");
+    if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_node_records: 0 (binary records only) or 1 (two-level records too)");
     t->tracer->SetNodeRecords(mode);
     return CPT_OK;
 }
@@ -633,7 +633,7 @@ int cpt_multi_set_traversal(cpt_multi *m, int mode) {
 }
 int cpt_multi_set_node_records(cpt_multi *m, int mode) {
     MULTI_OR_FAIL(m);
-    if (mode < -1 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_multi_set_node_records: -1 (by scene size), 0 (binary only) or 1 (two-level too)");
+    if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_multi_set_node_records: 0 (binary records only) or 1 (two-level records too)");
     m->tracer->SetNodeRecords(mode);
     return CPT_OK;
 }

@@ -59,10 +59,9 @@ struct Flow {
     // enters or leaves an instance); any: it is a shadow ray (AccelTop::Occlude, accel.cuh:152-173) and not
     // an extension ray (AccelTop::Intersect, accel.cuh:124-150).  A lane whose ray ends is left with
     // walking() false.  Returns false, in every lane, when no lane of the wave had a step to take.
-    template <class Stack, class World, bool WIDE = false>
+    template <class Stack, class World>
     __device__ inline bool step(const SceneDev &sc, Stack &st, LaneCounters &cnt, World world, bool any) {
-        constexpr bool FAST = Stack::kFast;        // the ordered traversal of trace.h (Traversal), same rules
-        static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
+        constexpr bool FAST = Stack::kFast, WIDE = Stack::kWide;        // the traversals of trace.h (Traversal), same rules
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;

@@ -115,7 +115,7 @@ private:
     std::vector<Shard> shards_;
     std::vector<std::unique_ptr<cpt::ShardComm>> comms_;     // one per distinct device, in order of first appearance
     std::vector<int> comm_shard_;                            // comm rank -> leader shard
-    int max_depth_ = -1, integrator_ = 3, channel_ = 0, wavefront_tail_ = 3, traversal_ = 0, node_records_ = -1;
+    int max_depth_ = -1, integrator_ = 3, channel_ = 0, wavefront_tail_ = 3, traversal_ = 0, node_records_ = 1;
     uint32_t samples_per_launch_ = 32;
     bool built_ = false;
     float last_ms_ = 0.0f;

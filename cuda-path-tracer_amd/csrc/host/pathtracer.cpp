@@ -169,9 +169,7 @@ void PathTracer::BuildAccel() {
     uint32_t num_instances = (uint32_t)instance_mesh_.size();
     if (num_instances == 0) return;
 
-    size_t scene_triangles = 0;
-    scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { scene_triangles += mesh.GetMesh()->IndicesCount() / 3; });
-    const bool wide = node_records_ > 0 || (node_records_ < 0 && scene_triangles >= kLargeSceneTriangles);
+    const bool wide = node_records_ != 0;
     // mesh descriptor table; the pack kernels fill in each root afterwards
     std::vector<cpt::MeshDev> mesh_table(meshes_.size());
     for (size_t i = 0; i < meshes_.size(); i++) {
@@ -212,8 +210,8 @@ void PathTracer::BuildAccel() {
         rc_check(cpt::lbvh_pack(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.tris.TypedGpuData<cpt::TriRecord>(), root,
                                 mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles,
                                 mb.indices.TypedGpuData<uint32_t>(), mb.positions.TypedGpuData<V3>(), stream_), "pack bottom level");
-        if (wide) rc_check(cpt::lbvh_pack_wide(mb.wide_nodes.TypedGpuData<cpt::PackedNode>(), mb.nodes.TypedGpuData<cpt::AccelNode>(),
-                                               mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles, false, stream_), "pack bottom level, two-level records");
+        if (wide) rc_check(cpt::lbvh_pack_wide(mb.wide_nodes.TypedGpuData<cpt::PackedNode>(), mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.num_triangles, stream_),
+                           "pack bottom level, two-level records");
     }
 
     // top level (pathtracer.cpp:120-154)
@@ -243,8 +241,8 @@ void PathTracer::BuildAccel() {
     scene_dev_.wide_nodes = 0;
     if (wide) {
         top_wide_.Allocate(sizeof(cpt::PackedNode) * 2 * (num_instances > 1 ? num_instances - 1 : 1));
-        rc_check(cpt::lbvh_pack_wide(top_wide_.TypedGpuData<cpt::PackedNode>(), top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(),
-                                     num_instances, true, stream_), "pack top level, two-level records");
+        rc_check(cpt::lbvh_pack_wide(top_wide_.TypedGpuData<cpt::PackedNode>(), top_packed_.TypedGpuData<cpt::PackedNode>(), num_instances, stream_),
+                 "pack top level, two-level records");
         scene_dev_.top_wide = top_wide_.TypedGpuData<cpt::PackedNode>();
         scene_dev_.wide_nodes = 1;
     }
@@ -452,8 +450,8 @@ void PathTracer::LaunchWavefront(const cpt::RenderParams &p) {
         wf_.segments = (uint32_t)segments;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        wf_resident_blocks_ = cpt::wavefront_resident_blocks(device, wf_dense_);
-        wf_finish_blocks_ = cpt::wavefront_finish_resident_blocks(device);
+        wf_resident_blocks_ = cpt::wavefront_resident_blocks(device, wf_dense_, scene_dev_.wide_nodes != 0);
+        wf_finish_blocks_ = cpt::wavefront_finish_resident_blocks(device, scene_dev_.wide_nodes != 0);
     }
     const uint32_t resident = (uint32_t)wf_resident_blocks_;
     rc_check(cpt::wavefront_begin_sample(scene_dev_, p, wf_, stream_), "wavefront generate");
@@ -495,17 +493,17 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         return;
     }
     const int variant = integrator == 4 ? 1 : (integrator == 5 ? 2 : 0);
-    const bool fast = scene_dev_.fast_traversal != 0;
-    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_fast_ != fast) {
+    const int fast = scene_dev_.fast_traversal != 0 ? 1 : (scene_dev_.wide_nodes != 0 ? 2 : 0);      // traversal of the kernel build
+    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_traversal_ != fast) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, fast);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, fast == 1, fast == 2);
         resident_dense_ = wf_dense_;
         resident_variant_ = variant;
-        resident_fast_ = fast;
+        resident_traversal_ = fast;
     }
     rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, variant, stream_), "render");
     queue_parity_ ^= 1u;

@@ -44,9 +44,9 @@ public:
     void SetTraversal(int mode) { scene_dev_.fast_traversal = mode ? 1 : 0; }
     int Traversal() const { return scene_dev_.fast_traversal; }
     // Two-level node records next to the binary ones (128 bytes per internal node: the node's grandchildren in the order
-    // the reference reaches them), walked by the exact traversal of the kernels for large scenes (batch queries,
-    // integrators 2 and 4): half as many dependent record fetches per ray, the same leaves in the same order.
-    // -1: from 65,536 triangles on (default); 0: never; 1: always.  Takes effect at the next BuildBuffers.
+    // the reference reaches them), walked by the exact traversal of every kernel: half as many dependent record fetches
+    // and traversal trips per ray, the same leaves in the same order.  1: built (default); 0: binary records only.
+    // Takes effect at the next BuildBuffers.
     void SetNodeRecords(int mode) { node_records_ = mode; }
     bool HasTwoLevelRecords() const { return scene_dev_.wide_nodes != 0; }
     // 0: persistent lane-regenerating megakernel (default); 1: one path per lane, one lane per pixel;
@@ -139,7 +139,7 @@ private:
     bool wf_dense_ = false;          // set by BuildBuffers from the scene's triangle count: which build of the persistent kernels runs
     bool resident_dense_ = false;
     int resident_variant_ = 0;
-    bool resident_fast_ = false;
+    int resident_traversal_ = -1;      // 0 exact on binary records, 1 ordered, 2 exact on two-level records
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
     float leaf_boxes_ms_ = 0.0f, pack_ms_ = 0.0f;
@@ -151,7 +151,7 @@ private:
     std::vector<uint32_t> instance_mesh_;            // instance -> mesh table index
     cpt::HipBuffer leaf_scratch_;
     cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_, top_wide_;
-    int node_records_ = -1;
+    int node_records_ = 1;
     cpt::HipBuffer mesh_table_, instance_table_, material_table_, light_table_, counters_;
     cpt::HipBuffer texel_pool_, texture_table_, srgb_table_;
     uint32_t num_lights_ = 0;

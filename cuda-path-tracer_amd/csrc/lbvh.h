@@ -52,8 +52,8 @@ int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions
 int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const AccelNode *nodes, const Bbox *bboxes, uint32_t num_primitives,
               const uint32_t *indices, const V3 *positions, hipStream_t stream);
 
-// Two-level records (two PackedNode per internal node: the right child's half, then the left child's) of a finished
-// build; nothing to do for a single primitive.
-int lbvh_pack_wide(PackedNode *out_wide, const AccelNode *nodes, const Bbox *bboxes, uint32_t num_primitives, bool top_level, hipStream_t stream);
+// Two-level records (two PackedNode per internal node: the right child's half, then the left child's) from the binary
+// records lbvh_pack wrote; nothing to do for a single primitive.
+int lbvh_pack_wide(PackedNode *out_wide, const PackedNode *packed_nodes, uint32_t num_primitives, hipStream_t stream);
 
 }  // namespace cpt

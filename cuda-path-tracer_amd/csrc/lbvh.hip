@@ -934,33 +934,41 @@ __global__ void __launch_bounds__(kBlock) k_pack_nodes(PackedNode *__restrict__ 
 // Two levels of the tree per record: internal node i becomes two 64-byte halves in the layout of PackedNode, the first
 // for its right child, the second for its left child.  A half holds the child itself when the child is a leaf (second
 // slot empty: reference kNoChild), otherwise the child's two children, right one first.  The four slots are in the
-// order the reference's traversal (right child first, accel.cuh:84-91) reaches them.
+// order the reference's traversal (right child first, accel.cuh:84-91) reaches them.  Made from the binary records:
+// node i's own record has its children's boxes, a child's record has the grandchildren's (three 64-byte reads, the
+// children's mostly from lines a neighbouring lane reads too).
 constexpr uint32_t kNoChild = 0xffffffffu;
-__global__ void __launch_bounds__(kBlock) k_pack_wide(PackedNode *__restrict__ out, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes,
-                                                       uint32_t n, int top_level) {
+__global__ void __launch_bounds__(kBlock) k_pack_wide(PackedNode *__restrict__ out, const PackedNode *__restrict__ packed, uint32_t n) {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (n < 2 || i >= n - 1) return;
-    const AccelNode nd = nodes[i];
-    auto half = [&](uint32_t c, float4 *o) {
-        Bbox a, b;
-        uint32_t ra, rb = kNoChild;
-        b.pmin = V4{0.0f, 0.0f, 0.0f, 0.0f}; b.pmax = b.pmin;
-        if (c >= n - 1) {
-            a = bboxes[c];
-            ra = child_ref(c, nodes, n, top_level);
-        } else {
-            const AccelNode cn = nodes[c];
-            a = bboxes[cn.rc]; ra = child_ref(cn.rc, nodes, n, top_level);
-            b = bboxes[cn.lc_or_id]; rb = child_ref(cn.lc_or_id, nodes, n, top_level);
-        }
-        o[0] = make_float4(a.pmin.x, a.pmin.y, a.pmin.z, a.pmax.x);
-        o[1] = make_float4(a.pmax.y, a.pmax.z, b.pmin.x, b.pmin.y);
-        o[2] = make_float4(b.pmin.z, b.pmax.x, b.pmax.y, b.pmax.z);
-        o[3] = make_float4(__uint_as_float(ra), __uint_as_float(rb), 0.0f, 0.0f);
-    };
+    const float4 *own = reinterpret_cast<const float4 *>(packed + i);
+    const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
+    const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
     float4 *o = reinterpret_cast<float4 *>(out + 2 * (size_t)i);
-    half(nd.rc, o);
-    half(nd.lc_or_id, o + 4);
+    auto half_of_internal = [&](uint32_t c, float4 *h) {     // the child's record with its two slots swapped
+        const float4 *q = reinterpret_cast<const float4 *>(packed + c);
+        const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+        h[0] = make_float4(c1.z, c1.w, c2.x, c2.y);
+        h[1] = make_float4(c2.z, c2.w, c0.x, c0.y);
+        h[2] = make_float4(c0.z, c0.w, c1.x, c1.y);
+        h[3] = make_float4(c3.y, c3.x, 0.0f, 0.0f);
+    };
+    if (rref & kLeafBit) {
+        o[0] = make_float4(p1.z, p1.w, p2.x, p2.y);
+        o[1] = make_float4(p2.z, p2.w, 0.0f, 0.0f);
+        o[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        o[3] = make_float4(__uint_as_float(rref), __uint_as_float(kNoChild), 0.0f, 0.0f);
+    } else {
+        half_of_internal(rref, o);
+    }
+    if (lref & kLeafBit) {
+        o[4] = make_float4(p0.x, p0.y, p0.z, p0.w);
+        o[5] = make_float4(p1.x, p1.y, 0.0f, 0.0f);
+        o[6] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        o[7] = make_float4(__uint_as_float(lref), __uint_as_float(kNoChild), 0.0f, 0.0f);
+    } else {
+        half_of_internal(lref, o + 4);
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) k_pack_tris(TriRecord *__restrict__ out, const AccelNode *__restrict__ nodes, const uint32_t *__restrict__ indices,
@@ -1195,9 +1203,9 @@ int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const
     return (int)hipGetLastError();
 }
 
-int lbvh_pack_wide(PackedNode *out_wide, const AccelNode *nodes, const Bbox *bboxes, uint32_t n, bool top_level, hipStream_t stream) {
+int lbvh_pack_wide(PackedNode *out_wide, const PackedNode *packed, uint32_t n, hipStream_t stream) {
     if (n < 2) return 0;
-    hipLaunchKernelGGL(k_pack_wide, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, out_wide, nodes, bboxes, n, top_level ? 1 : 0);
+    hipLaunchKernelGGL(k_pack_wide, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, out_wide, packed, n);
     return (int)hipGetLastError();
 }
 

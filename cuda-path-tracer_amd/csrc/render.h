@@ -24,7 +24,7 @@ constexpr uint32_t kRegenQueueWords = 2 * kCursorSetWords;
 // mean into a film whose alpha is 0 or 1 everywhere) or p.order must point to
 // width * height zeroed words.  The film ends up bit for bit as after one launch per sample.
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream);
-int render_regen_resident_blocks(int device, bool dense, int variant, bool fast);
+int render_regen_resident_blocks(int device, bool dense, int variant, bool fast, bool wide);
 
 // Compares the traversal's reciprocal-based exact division with the hardware division on at least
 // `pairs` operand pairs; adds the number of differing results to *d_mismatches (device memory).

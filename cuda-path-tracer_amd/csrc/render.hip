@@ -9,13 +9,15 @@
 #include "path_lane.h"
 #include "segment_fetch.h"
 
+#include <type_traits>
+
 namespace cpt {
 
 namespace {
 
 // src/kernels/integrator/path.cu:9-83
-template <bool MAPS>
-__device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, TraceStack &st, LaneCounters &cnt) {
+template <bool MAPS, class Stack>
+__device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, Stack &st, LaneCounters &cnt) {
     Hit hit;
     float tmax = kRayTMax;
     if (!trace<false>(sc, true, ro, rd, kRayTMin, tmax, hit, st, cnt)) return v3(0.0f);
@@ -85,12 +87,12 @@ __device__ inline uint32_t xcd_band_remap(uint32_t b, uint32_t nb) {
 }
 
 // one workgroup = one 16x16 pixel tile, one wave = one 8x8 sub-tile
-template <bool MAPS>
+template <bool MAPS, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParams p) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStack st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kLdsStackEntries, 1, false, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t tiles_x = (p.width + 15) / 16;
     const uint32_t tile = xcd_band_remap(blockIdx.x, gridDim.x);
@@ -120,12 +122,12 @@ __global__ void __launch_bounds__(kTraceBlock) k_render(SceneDev sc, RenderParam
 // 187 -> 199 Mpaths/s; cornell-box-glass, all L1 hits, is 10 % slower that way and keeps the other build).
 template <bool DENSE> struct RegenShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 12 : 16; };
 
-template <bool MAPS, bool DENSE>
+template <bool MAPS, bool DENSE, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_render_regen(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[RegenShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<RegenShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<RegenShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, false, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -179,13 +181,13 @@ constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spille
 #endif
 constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
-template <bool MAPS, bool FAST, bool WIDE = false>
+template <bool MAPS, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene, FAST> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
+    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene, FAST, WIDE> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
     LaneCounters cnt;
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = s.has_shadow;
             auto world = [&](V3 &ow, V3 &dw) { ow = s.l.ro; dw = shadow ? s.shadow_dir : s.l.rd; };
-            const bool moved = t.template step<decltype(st), decltype(world), WIDE>(sc, st, cnt, world, shadow);
+            const bool moved = t.step(sc, st, cnt, world, shadow);
             if (moved && (trip & 15u) != 15u) continue;
             if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
@@ -296,7 +298,7 @@ constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned
 #ifdef CPT_STEP_STATS
 __device__ unsigned long long g_step_stats[18];
 #endif
-template <bool MAPS, bool DENSE, bool FAST>
+template <bool MAPS, bool DENSE, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     auto pool = [&](uint32_t field, uint32_t slot) -> float4 & { return s_pool[4 * slot + field]; };
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
 #ifdef CPT_STEP_STATS
     StepStats stats;
@@ -360,17 +362,18 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         job = 0xffffffffu;
         s.ext_traced = s.l.alive && s.has_ext;
         t = Flow();                                     // nothing of the last bounce's walks is carried over
-        if (s.ext_traced) t.begin(sc, s.l.ro, s.l.rd, kRayTMax, Flow::prepare<FAST>(sc, s.l.ro, s.l.rd, kRayTMax), cnt);
+        if (s.ext_traced) t.template begin<WIDE>(sc, s.l.ro, s.l.rd, kRayTMax, Flow::prepare<FAST>(sc, s.l.ro, s.l.rd, kRayTMax), cnt);
         bool own = s.ext_traced;                        // the ray in `t` is the lane's own extension ray
         uint32_t pool_next = 0;
 
         // ---- walk; lanes without a ray take shadow rays from the list
         for (uint32_t trip = 0;; trip++) {
             const bool shadow = !own;
-            const bool moved = t.step(sc, st, cnt, [&](V3 &ow, V3 &dw) {
+            auto world = [&](V3 &ow, V3 &dw) {
                 if (own) { ow = s.l.ro; dw = s.l.rd; }
                 else { float4 a = pool(0, wave_base + job), b = pool(1, wave_base + job); ow = v3(a.x, a.y, a.z); dw = v3(b.x, b.y, b.z); }
-            }, shadow);
+            };
+            const bool moved = t.step(sc, st, cnt, world, shadow);
             if (moved && (trip & kPoolPeriodMask) != kPoolPeriodMask) continue;
             const bool free_lane = !t.walking();
             if (free_lane && own) { ext_found = t.found; ext_hit = t.hit; own = false; }
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
                 q.r = v3(c.x, c.y, c.z);
                 q.fast = __float_as_uint(b.w) != 0u;
                 q.enters = true;                        // rays that miss the scene's box are not listed
-                t.begin(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, q, cnt, false);      // counted when it was listed
+                t.template begin<WIDE>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, q, cnt, false);      // counted when it was listed
             }
             pool_next += min((uint32_t)__popcll(free_mask), avail);
             if (__ballot(t.walking()) == 0ull && pool_next == pool_count) break;
@@ -446,13 +449,13 @@ constexpr int kQueryLdsEntries = 8;
 // with 1 or 2, 2.46 with 4) while diverging ones gain (soup 1M: 0.67 with 1, 0.75 with 2, 0.81 with 4)
 constexpr int kQueryLeafWeightLargeScene = 2;
 
-template <bool LARGE, bool FAST, bool WIDE = false>
+template <bool LARGE, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_first_hit(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint32_t *__restrict__ inst_out,
                                                             uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWa
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        bool ok = trace<false, decltype(st), WIDE>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
+        bool ok = trace<false>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt);
         inst_out[i] = ok ? hit.inst : 0xffffffffu;
         prim_out[i] = ok ? hit.prim : 0xffffffffu;
         if (t_out) t_out[i] = tmax;
@@ -469,12 +472,12 @@ __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWa
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
-template <bool LARGE, bool FAST, bool WIDE = false>
+template <bool LARGE, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     unsigned long long i = (unsigned long long)blockIdx.x * kTraceBlock + threadIdx.x;
     if (i < n) {
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWa
         float4 a = r[0], b = r[1];
         Hit hit;
         float tmax = b.w;
-        out[i] = trace<true, decltype(st), WIDE>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
+        out[i] = trace<true>(sc, true, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, tmax, hit, st, cnt) ? 1 : 0;
     }
     flush_counters(sc, cnt, 0u, s_cnt);
 }
@@ -594,11 +597,30 @@ int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_misma
     return (int)hipGetLastError();
 }
 
+// ---- kernel builds by (material maps, large scene, traversal).  Traversal: exact on the binary records, exact on the
+// two-level records (when the scene has them), or ordered (binary records).  Integrators without an ordered build
+// run exact.
+template <class F> auto pick(bool v, F &&f) { return v ? f(std::true_type{}) : f(std::false_type{}); }
+
+using RegenKernel = void (*)(SceneDev, RenderParams, uint32_t *, uint32_t);
+RegenKernel regen_kernel(int variant, bool maps, bool dense, bool fast, bool wide) {
+    return pick(maps, [&](auto M) {
+        return pick(dense, [&](auto D) -> RegenKernel {
+            constexpr bool m = decltype(M)::value, d = decltype(D)::value;
+            if (variant == 2) return fast ? k_render_pool<m, d, true, false> : wide ? k_render_pool<m, d, false, true> : k_render_pool<m, d, false, false>;
+            if (variant == 1) return fast ? k_render_flow<m, true, false> : wide ? k_render_flow<m, false, true> : k_render_flow<m, false, false>;
+            return wide ? k_render_regen<m, d, true> : k_render_regen<m, d, false>;
+        });
+    });
+}
+
 int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream) {
     uint32_t tiles = ((p.width + 15) / 16) * ((p.height + 15) / 16);
     if (tiles == 0) return 0;
-    if (sc.textures) hipLaunchKernelGGL(k_render<true>, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
-    else hipLaunchKernelGGL(k_render<false>, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
+    void (*kernel)(SceneDev, RenderParams) = pick(sc.textures != nullptr, [&](auto M) {
+        return sc.wide_nodes ? k_render<decltype(M)::value, true> : k_render<decltype(M)::value, false>;
+    });
+    hipLaunchKernelGGL(kernel, dim3(tiles), dim3(kTraceBlock), 0, stream, sc, p);
     return (int)hipGetLastError();
 }
 
@@ -610,66 +632,15 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     if ((unsigned long long)tiles * p.spp_count * kSegmentSlots > 0xffffffffull) return (int)hipErrorInvalidValue;
     unsigned long long want = ((unsigned long long)tiles * p.spp_count + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;
-    const dim3 grid(blocks), block(kTraceBlock);
-    const bool fast = sc.fast_traversal != 0;
-    if (variant == 2) {
-        // kernel build by (material maps, large scene, ordered traversal)
-        const int which = (sc.textures ? 4 : 0) | (dense ? 2 : 0) | (fast ? 1 : 0);
-        switch (which) {
-            case 0: hipLaunchKernelGGL((k_render_pool<false, false, false>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 1: hipLaunchKernelGGL((k_render_pool<false, false, true>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 2: hipLaunchKernelGGL((k_render_pool<false, true, false>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 3: hipLaunchKernelGGL((k_render_pool<false, true, true>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 4: hipLaunchKernelGGL((k_render_pool<true, false, false>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 5: hipLaunchKernelGGL((k_render_pool<true, false, true>), grid, block, 0, stream, sc, p, queue, parity); break;
-            case 6: hipLaunchKernelGGL((k_render_pool<true, true, false>), grid, block, 0, stream, sc, p, queue, parity); break;
-            default: hipLaunchKernelGGL((k_render_pool<true, true, true>), grid, block, 0, stream, sc, p, queue, parity); break;
-        }
-        return (int)hipGetLastError();
-    }
-    if (variant == 1) {
-        if (sc.wide_nodes && !fast) {
-            if (sc.textures) hipLaunchKernelGGL((k_render_flow<true, false, true>), grid, block, 0, stream, sc, p, queue, parity);
-            else hipLaunchKernelGGL((k_render_flow<false, false, true>), grid, block, 0, stream, sc, p, queue, parity);
-            return (int)hipGetLastError();
-        }
-        if (sc.textures) {
-            if (fast) hipLaunchKernelGGL((k_render_flow<true, true>), grid, block, 0, stream, sc, p, queue, parity);
-            else hipLaunchKernelGGL((k_render_flow<true, false>), grid, block, 0, stream, sc, p, queue, parity);
-        } else {
-            if (fast) hipLaunchKernelGGL((k_render_flow<false, true>), grid, block, 0, stream, sc, p, queue, parity);
-            else hipLaunchKernelGGL((k_render_flow<false, false>), grid, block, 0, stream, sc, p, queue, parity);
-        }
-        return (int)hipGetLastError();
-    }
-    if (sc.textures) {
-        if (dense) hipLaunchKernelGGL((k_render_regen<true, true>), grid, block, 0, stream, sc, p, queue, parity);
-        else hipLaunchKernelGGL((k_render_regen<true, false>), grid, block, 0, stream, sc, p, queue, parity);
-    } else {
-        if (dense) hipLaunchKernelGGL((k_render_regen<false, true>), grid, block, 0, stream, sc, p, queue, parity);
-        else hipLaunchKernelGGL((k_render_regen<false, false>), grid, block, 0, stream, sc, p, queue, parity);
-    }
+    RegenKernel kernel = regen_kernel(variant, sc.textures != nullptr, dense, sc.fast_traversal != 0, sc.wide_nodes != 0);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device, bool dense, int variant, bool fast) {
+int render_regen_resident_blocks(int device, bool dense, int variant, bool fast, bool wide) {
     int per_cu = 0, other = 0, cus = 0;
-    const void *with_maps = dense ? (const void *)k_render_regen<true, true> : (const void *)k_render_regen<true, false>;
-    const void *without = dense ? (const void *)k_render_regen<false, true> : (const void *)k_render_regen<false, false>;
-    if (variant == 1) {
-        with_maps = fast ? (const void *)k_render_flow<true, true> : (const void *)k_render_flow<true, false>;
-        without = fast ? (const void *)k_render_flow<false, true> : (const void *)k_render_flow<false, false>;
-    } else if (variant == 2) {
-        if (fast) {
-            with_maps = dense ? (const void *)k_render_pool<true, true, true> : (const void *)k_render_pool<true, false, true>;
-            without = dense ? (const void *)k_render_pool<false, true, true> : (const void *)k_render_pool<false, false, true>;
-        } else {
-            with_maps = dense ? (const void *)k_render_pool<true, true, false> : (const void *)k_render_pool<true, false, false>;
-            without = dense ? (const void *)k_render_pool<false, true, false> : (const void *)k_render_pool<false, false, false>;
-        }
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, with_maps, kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, without, kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)regen_kernel(variant, true, dense, fast, wide), kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, (const void *)regen_kernel(variant, false, dense, fast, wide), kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
     if (other < per_cu) per_cu = other;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return per_cu * cus;
@@ -679,18 +650,13 @@ int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    const dim3 grid((uint32_t)blocks), block(kTraceBlock);
     const unsigned long long count = n;
-    if (sc.wide_nodes && !sc.fast_traversal) {
-        hipLaunchKernelGGL((k_first_hit<true, false, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv);
-        return (int)hipGetLastError();
-    }
-    switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
-        case 0: hipLaunchKernelGGL((k_first_hit<false, false>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
-        case 1: hipLaunchKernelGGL((k_first_hit<false, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
-        case 2: hipLaunchKernelGGL((k_first_hit<true, false>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
-        default: hipLaunchKernelGGL((k_first_hit<true, true>), grid, block, 0, stream, sc, rays, count, inst, prim, t, uv); break;
-    }
+    const bool fast = sc.fast_traversal != 0, wide = sc.wide_nodes != 0;
+    void (*kernel)(SceneDev, const float *, unsigned long long, uint32_t *, uint32_t *, float *, float *) = pick(sc.large_scene != 0, [&](auto L) {
+        constexpr bool l = decltype(L)::value;
+        return fast ? k_first_hit<l, true, false> : wide ? k_first_hit<l, false, true> : k_first_hit<l, false, false>;
+    });
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, count, inst, prim, t, uv);
     return (int)hipGetLastError();
 }
 
@@ -698,18 +664,13 @@ int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *o
     if (n == 0) return 0;
     uint64_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
     if (blocks > 0x7fffffffull) return (int)hipErrorInvalidValue;
-    const dim3 grid((uint32_t)blocks), block(kTraceBlock);
     const unsigned long long count = n;
-    if (sc.wide_nodes && !sc.fast_traversal) {
-        hipLaunchKernelGGL((k_occlude<true, false, true>), grid, block, 0, stream, sc, rays, count, out);
-        return (int)hipGetLastError();
-    }
-    switch ((sc.large_scene ? 2 : 0) | (sc.fast_traversal ? 1 : 0)) {
-        case 0: hipLaunchKernelGGL((k_occlude<false, false>), grid, block, 0, stream, sc, rays, count, out); break;
-        case 1: hipLaunchKernelGGL((k_occlude<false, true>), grid, block, 0, stream, sc, rays, count, out); break;
-        case 2: hipLaunchKernelGGL((k_occlude<true, false>), grid, block, 0, stream, sc, rays, count, out); break;
-        default: hipLaunchKernelGGL((k_occlude<true, true>), grid, block, 0, stream, sc, rays, count, out); break;
-    }
+    const bool fast = sc.fast_traversal != 0, wide = sc.wide_nodes != 0;
+    void (*kernel)(SceneDev, const float *, unsigned long long, uint8_t *) = pick(sc.large_scene != 0, [&](auto L) {
+        constexpr bool l = decltype(L)::value;
+        return fast ? k_occlude<l, true, false> : wide ? k_occlude<l, false, true> : k_occlude<l, false, false>;
+    });
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, count, out);
     return (int)hipGetLastError();
 }
 

@@ -49,12 +49,15 @@ __device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return mak
 // LDS_ENTRIES * kTraceBlock entries and a local array of kSpillEntries); this holds their addresses.
 // LEAF_WEIGHT rides along because it is, like the stack's shape, a choice each kernel build makes for the
 // scenes it is meant for (see Traversal::vote_step).
-// FAST selects the ordered traversal (see Traversal) and rides along for the same reason.
-template <int LDS_ENTRIES, int LEAF_WEIGHT = 1, bool FAST = false>
+// FAST selects the ordered traversal (see Traversal) and rides along for the same reason; so does WIDE, which selects
+// the two-level node records (exact traversal only).
+template <int LDS_ENTRIES, int LEAF_WEIGHT = 1, bool FAST = false, bool WIDE = false>
 struct TraceStackT {
     static constexpr int kLdsEntries = LDS_ENTRIES;
     static constexpr int kLeafWeight = LEAF_WEIGHT;
     static constexpr bool kFast = FAST;
+    static constexpr bool kWide = WIDE;
+    static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
     LdsStack lds;
     PrivateStack spill;
     Counters *counters;       // where an entry that does not fit is reported (may be null)
@@ -322,10 +325,9 @@ struct Traversal {
     __device__ inline bool live() const { return cur != kNoNode; }
 
     // returns false when no lane of the wave that called it has work left
-    template <bool ANY, class Stack, bool WIDE = false>
+    template <bool ANY, class Stack>
     __device__ inline bool vote_step(const SceneDev &sc, Stack &st, LaneCounters &cnt) {
-        constexpr bool FAST = Stack::kFast;
-        static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
+        constexpr bool FAST = Stack::kFast, WIDE = Stack::kWide;
         const bool alive = cur != kNoNode;
         const bool is_node = alive && !(cur & kLeafBit);
         const bool is_tri = alive && (cur & kLeafBit) && in_blas;
@@ -446,11 +448,11 @@ struct Traversal {
 // One ray per lane, all lanes of the wave that reach the call together (`active` = false for
 // lanes with nothing to trace); returns when every lane's ray is finished.  tmax is updated to
 // the hit distance on closest hits.
-template <bool ANY, class Stack, bool WIDE = false>
+template <bool ANY, class Stack>
 __device__ inline bool trace(const SceneDev &sc, bool active, V3 ow, V3 dw, float tmin, float &tmax, Hit &hit, Stack &st, LaneCounters &cnt) {
     Traversal t;
-    if (active) t.begin<Stack::kFast, WIDE>(sc, ow, dw, tmin, tmax, cnt);
-    while (t.vote_step<ANY, Stack, WIDE>(sc, st, cnt)) {}
+    if (active) t.begin<Stack::kFast, Stack::kWide>(sc, ow, dw, tmin, tmax, cnt);
+    while (t.vote_step<ANY>(sc, st, cnt)) {}
     if (!ANY && t.found) { hit = t.hit; tmax = t.tmax; }
     return t.found;
 }

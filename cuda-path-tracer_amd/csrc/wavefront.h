@@ -37,8 +37,8 @@ struct WavefrontBuffers {
 size_t wavefront_slots(uint32_t width, uint32_t height);
 // workgroups of a queue traversal kernel the device holds at once; dense = the build with more waves per
 // SIMD and a shorter LDS stack, meant for scenes whose BVH does not fit the vector L1
-int wavefront_resident_blocks(int device, bool dense);
-int wavefront_finish_resident_blocks(int device);   // same for the finishing kernel
+int wavefront_resident_blocks(int device, bool dense, bool wide);
+int wavefront_finish_resident_blocks(int device, bool wide);   // same for the finishing kernel
 // camera rays + fresh path state for sample p.spp; fills the queue
 int wavefront_begin_sample(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, hipStream_t stream);
 // one bounce: extend the queued rays, shade (refills the queue and the shadow queue), trace shadow

@@ -16,6 +16,8 @@
 #include "path_lane.h"
 #include "segment_fetch.h"
 
+#include <type_traits>
+
 namespace cpt {
 
 namespace {
@@ -57,12 +59,12 @@ __global__ void __launch_bounds__(256) k_wf_generate(SceneDev sc, RenderParams p
 // ray, result to wb.hit.  ANY = true: the path's shadow ray; an unoccluded ray adds the pending
 // light contribution to the path's colour, and a path that was only waiting for this ray is
 // written to the film.
-template <bool ANY, bool DENSE, bool WIDE = false>
+template <bool ANY, bool DENSE, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, WIDE ? 5 : QueueTraceShape<DENSE>::kWaves) k_wf_trace(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[QueueTraceShape<DENSE>::kLdsEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<QueueTraceShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, false, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(kTraceBlock, WIDE ? 5 : QueueTraceShape<DENSE>
             }
         }
         if (__ballot(have) == 0ull) break;
-        t.template vote_step<ANY, decltype(st), WIDE>(sc, st, cnt);
+        t.template vote_step<ANY>(sc, st, cnt);
         if (have && !t.live()) {
             if (ANY) {
                 float4 c = wb.col[path];
@@ -233,12 +235,12 @@ __global__ void __launch_bounds__(256) k_wf_shade(SceneDev sc, RenderParams p, W
 
 // Finishes what the queue still holds: lanes load a queued path's state and run it to its end
 // in registers, picking up another queued path whenever one ends.
-template <bool MAPS>
+template <bool MAPS, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, 4) k_wf_finish(SceneDev sc, RenderParams p, WavefrontBuffers wb) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     uint2 spill_entries[kSpillEntries];
-    TraceStack st(s_stack, spill_entries, sc.counters);
+    TraceStackT<kLdsStackEntries, 1, false, WIDE> st(s_stack, spill_entries, sc.counters);
     LaneCounters cnt;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -289,15 +291,27 @@ static int resident_blocks_of(const void *const *kernels, int count, int device)
     return best * cus;
 }
 
-int wavefront_resident_blocks(int device, bool dense) {
-    const void *sparse_kernels[2] = {(const void *)k_wf_trace<false, false>, (const void *)k_wf_trace<true, false>};
-    const void *dense_kernels[4] = {(const void *)k_wf_trace<false, true>, (const void *)k_wf_trace<true, true>, (const void *)k_wf_trace<false, true, true>,
-                                    (const void *)k_wf_trace<true, true, true>};
-    return dense ? resident_blocks_of(dense_kernels, 4, device) : resident_blocks_of(sparse_kernels, 2, device);
+template <class F> static auto pick(bool v, F &&f) { return v ? f(std::true_type{}) : f(std::false_type{}); }
+using QueueTraceKernel = void (*)(SceneDev, RenderParams, WavefrontBuffers);
+static QueueTraceKernel trace_kernel(bool any, bool dense, bool wide) {
+    return pick(any, [&](auto A) {
+        return pick(dense, [&](auto D) -> QueueTraceKernel {
+            constexpr bool a = decltype(A)::value, d = decltype(D)::value;
+            return wide ? k_wf_trace<a, d, true> : k_wf_trace<a, d, false>;
+        });
+    });
+}
+static QueueTraceKernel finish_kernel(bool maps, bool wide) {
+    return pick(maps, [&](auto M) -> QueueTraceKernel { return wide ? k_wf_finish<decltype(M)::value, true> : k_wf_finish<decltype(M)::value, false>; });
 }
 
-int wavefront_finish_resident_blocks(int device) {
-    const void *kernels[2] = {(const void *)k_wf_finish<false>, (const void *)k_wf_finish<true>};
+int wavefront_resident_blocks(int device, bool dense, bool wide) {
+    const void *kernels[2] = {(const void *)trace_kernel(false, dense, wide), (const void *)trace_kernel(true, dense, wide)};
+    return resident_blocks_of(kernels, 2, device);
+}
+
+int wavefront_finish_resident_blocks(int device, bool wide) {
+    const void *kernels[2] = {(const void *)finish_kernel(false, wide), (const void *)finish_kernel(true, wide)};
     return resident_blocks_of(kernels, 2, device);
 }
 
@@ -319,20 +333,15 @@ int wavefront_bounce(const SceneDev &sc, const RenderParams &p, const WavefrontB
                      hipStream_t stream) {
     const uint32_t blocks = persistent_blocks(wb, resident_blocks);
     const uint32_t shade_blocks = (wb.segments + 3) / 4;
-    if (sc.wide_nodes) hipLaunchKernelGGL((k_wf_trace<false, true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    else if (dense) hipLaunchKernelGGL((k_wf_trace<false, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    else hipLaunchKernelGGL((k_wf_trace<false, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    hipLaunchKernelGGL(trace_kernel(false, dense, sc.wide_nodes != 0), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     if (sc.textures) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
     else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, sc, p, wb, bounce_id);
-    if (sc.wide_nodes) hipLaunchKernelGGL((k_wf_trace<true, true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    else if (dense) hipLaunchKernelGGL((k_wf_trace<true, true>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    else hipLaunchKernelGGL((k_wf_trace<true, false>), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    hipLaunchKernelGGL(trace_kernel(true, dense, sc.wide_nodes != 0), dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 
 int wavefront_finish(const SceneDev &sc, const RenderParams &p, const WavefrontBuffers &wb, uint32_t resident_blocks, hipStream_t stream) {
-    if (sc.textures) hipLaunchKernelGGL(k_wf_finish<true>, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
-    else hipLaunchKernelGGL(k_wf_finish<false>, dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
+    hipLaunchKernelGGL(finish_kernel(sc.textures != nullptr, sc.wide_nodes != 0), dim3(persistent_blocks(wb, resident_blocks)), dim3(kTraceBlock), 0, stream, sc, p, wb);
     return (int)hipGetLastError();
 }
 

@@ -159,13 +159,13 @@ int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
  * cpt_tracer_first_hit / cpt_tracer_occlude and to integrators 3, 4 and 5; integrators 0, 1 and 2 always run exact. */
 int cpt_tracer_set_traversal(cpt_tracer *t, int mode);
 /* Node records of the exact traversal (no counterpart in the reference, which walks one AccelNode and two Bbox per step,
- * accel.cuh:68-90): next to the 64-byte binary records the build can lay down two-level records, 128 bytes per internal
+ * accel.cuh:68-90): next to the 64-byte binary records the build lays down two-level records, 128 bytes per internal
  * node holding the boxes and references of its (up to four) grandchildren in the order accel.cuh:84-91 reaches them.
- * A ray then fetches half as many dependent records; because a child's box lies inside its parent's and every
- * operation of BboxIntersect is monotonic in the box coordinates, testing the grandchildren directly walks exactly
- * the leaves the reference walks, in its order: results stay bit-exact.  Used by cpt_tracer_first_hit /
- * cpt_tracer_occlude and integrators 2 and 4 in exact traversal.  mode: -1 = from 65,536 triangles on (default),
- * 0 = never, 1 = always; takes effect at the next cpt_tracer_build_buffers. */
+ * A ray then fetches half as many dependent records in half as many traversal steps; because a child's box lies inside
+ * its parent's and every operation of BboxIntersect is monotonic in the box coordinates, testing the grandchildren
+ * directly walks exactly the leaves the reference walks, in its order: results stay bit-exact.  Every kernel walks them
+ * in exact traversal; the ordered traversal walks the binary records.  mode: 1 = built (default), 0 = binary records
+ * only (the exact traversal then walks those); takes effect at the next cpt_tracer_build_buffers. */
 int cpt_tracer_set_node_records(cpt_tracer *t, int mode);
 /* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
  * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette

@@ -17,6 +17,7 @@ depth = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 modes = sys.argv[7] if len(sys.argv) > 7 else "0"
 traversal = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 per_launch = int(sys.argv[9]) if len(sys.argv) > 9 else 32
+node_records = int(sys.argv[10]) if len(sys.argv) > 10 else 1
 t0 = time.time()
 objs, cam = synthetic_scene(kind, ntris)
 # a camera low over the terrain (inside the cube of the soup) so that nearly every 16:9 ray hits
@@ -30,6 +31,7 @@ sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
 t1 = time.time()
 tr = cpt.Tracer(sc, W, H, max_depth=depth)
 tr.set_traversal(traversal)
+tr.set_node_records(node_records)
 tr.set_samples_per_launch(per_launch)
 tr.build_buffers(profile=True)
 t2 = time.time()

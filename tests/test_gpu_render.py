@@ -211,8 +211,7 @@ def test_large_scene_builds_of_the_integrators_agree(cpt, kind, depth):
     for k in range(1, len(imgs)):
         assert np.array_equal(imgs[0].view(np.uint32), imgs[k].view(np.uint32)), k
         assert rays[0][:3] == rays[k][:3], k
-    # node records fetched: modes 0 and 5 walk the binary records, 2 and 4 (and 3, which is 4 here) the two-level ones
-    assert rays[0][3] == rays[4][3] and rays[2][3] == rays[3][3] and rays[3][3] < 0.62 * rays[0][3]
+        assert rays[0][3] == rays[k][3], k
     if kind == "heightfield":
         ref, _ = OracleScene(objs, cam).render(100, 60, 1, 5, depth)
         compare(imgs[0], ref)
@@ -465,8 +464,8 @@ def test_render_entry_point_at_the_kernel_level(cpt):
 
 
 def test_two_level_records_give_the_same_image(cpt):
-    """Integrators 2 (wavefront) and 4 (persistent megakernel for large scenes) with and without the two-level node
-    records: the same film bit for bit, the same rays and triangle tests."""
+    """Every integrator with and without the two-level node records: the same film bit for bit, the same rays and
+    triangle tests, about half the node records fetched."""
     objs, cam = synthetic_scene("heightfield", 120000)
     sc = cpt.Scene()
     for o in objs:
@@ -474,8 +473,8 @@ def test_two_level_records_give_the_same_image(cpt):
     W, H = 320, 192
     sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
     films, work = {}, {}
-    for records in (0, 1, -1):
-        for integrator in (2, 4):
+    for records in (0, 1):
+        for integrator in (0, 1, 2, 4, 5):
             tr = cpt.Tracer(sc, W, H, max_depth=6)
             tr.set_node_records(records)
             tr.set_integrator(integrator)
@@ -490,5 +489,4 @@ def test_two_level_records_give_the_same_image(cpt):
     for key, film in films.items():
         assert np.array_equal(film, ref), key
         assert work[key][:2] == work[(0, 4)][:2], key
-    assert work[(1, 4)][2] < 0.62 * work[(0, 4)][2]
-    assert work[(-1, 4)] == work[(1, 4)]                     # 120,000 triangles: past the size from which they are built
+        assert (work[key][2] == work[(0, 4)][2]) if key[0] == 0 else (work[key][2] < 0.62 * work[(0, 4)][2]), key

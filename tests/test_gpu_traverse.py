@@ -11,7 +11,7 @@ from helpers import *  # noqa: F403
 pytestmark = pytest.mark.gpu
 
 
-def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5, node_records=-1):
+def gpu_scene(cpt, objects, cam, width=64, height=64, max_depth=5, node_records=1):
     sc = cpt.Scene()
     for o in objects:
         sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
