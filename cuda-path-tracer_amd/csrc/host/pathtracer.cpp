@@ -493,14 +493,14 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
         return;
     }
     const int variant = integrator == 4 ? 1 : (integrator == 5 ? 2 : 0);
-    const int fast = scene_dev_.fast_traversal != 0 ? 1 : (scene_dev_.wide_nodes != 0 ? 2 : 0);      // traversal of the kernel build
+    const int fast = (scene_dev_.fast_traversal != 0 ? 1 : 0) | (scene_dev_.wide_nodes != 0 ? 2 : 0);      // traversal of the kernel build
     if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_traversal_ != fast) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, fast == 1, fast == 2);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, (fast & 1) != 0, (fast & 2) != 0);
         resident_dense_ = wf_dense_;
         resident_variant_ = variant;
         resident_traversal_ = fast;

@@ -139,7 +139,7 @@ private:
     bool wf_dense_ = false;          // set by BuildBuffers from the scene's triangle count: which build of the persistent kernels runs
     bool resident_dense_ = false;
     int resident_variant_ = 0;
-    int resident_traversal_ = -1;      // 0 exact on binary records, 1 ordered, 2 exact on two-level records
+    int resident_traversal_ = -1;      // bit 0: ordered traversal, bit 1: two-level records
     int wavefront_tail_ = 3;
     float build_stage_ms_[5] = {0, 0, 0, 0, 0};
     float leaf_boxes_ms_ = 0.0f, pack_ms_ = 0.0f;

@@ -57,7 +57,6 @@ struct TraceStackT {
     static constexpr int kLeafWeight = LEAF_WEIGHT;
     static constexpr bool kFast = FAST;
     static constexpr bool kWide = WIDE;
-    static_assert(!(WIDE && FAST), "two-level records are walked in the reference's order only");
     LdsStack lds;
     PrivateStack spill;
     Counters *counters;       // where an entry that does not fit is reported (may be null)
@@ -266,6 +265,19 @@ __device__ inline bool tri_test_or_tie(const TriRecord *rec, V3 o, V3 d, float t
 
 constexpr uint32_t kNoNode = 0xffffffffu;
 
+// Ordered traversal over a two-level record: the (up to four) slots that are hit, nearest first.  On return r[0] is
+// the slot to walk next (kNoNode: none was hit) and r[1..3] the ones to push, r[3] first; slots that were missed or
+// are empty come last with reference kNoNode and distance +inf.
+__device__ inline void order_slots(float t[4], uint32_t r[4]) {
+    auto nearer_first = [&](int a, int b) {
+        const bool swap = t[b] < t[a];
+        const float ta = swap ? t[b] : t[a], tb = swap ? t[a] : t[b];
+        const uint32_t ra = swap ? r[b] : r[a], rb = swap ? r[a] : r[b];
+        t[a] = ta; t[b] = tb; r[a] = ra; r[b] = rb;
+    };
+    nearer_first(0, 1); nearer_first(2, 3); nearer_first(0, 2); nearer_first(1, 3); nearer_first(1, 2);
+}
+
 // The wave runs the kind of step that has the most lanes, with lanes at a triangle or at an instance counted
 // Stack::kLeafWeight times: those are the rarer kinds, and a lane that waits at one until its kind outnumbers
 // the node walkers holds its ray back for many trips.  Measured with the weights 1, 2, 3, 4, 8: on scenes whose
@@ -348,6 +360,24 @@ struct Traversal {
                     const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6), b3 = load_f4(q, 7);
                     cnt.nodes++;
                     const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(b3.x), r3 = __float_as_uint(b3.y);
+                    if constexpr (FAST) {
+                        const float inf = __uint_as_float(0x7f800000u);
+                        float t[4];
+                        uint32_t r[4] = {r0, r1, r2, r3};
+                        const bool h0 = slab_fast(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, tmin, t[0]) && within_reach<true>(t[0], tmax, ANY);
+                        const bool h1 = r1 != kNoNode && slab_fast(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t[1]) && within_reach<true>(t[1], tmax, ANY);
+                        const bool h2 = slab_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t[2]) && within_reach<true>(t[2], tmax, ANY);
+                        const bool h3 = r3 != kNoNode && slab_fast(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, tmin, t[3]) && within_reach<true>(t[3], tmax, ANY);
+                        if (!h0) { t[0] = inf; r[0] = kNoNode; }
+                        if (!h1) { t[1] = inf; r[1] = kNoNode; }
+                        if (!h2) { t[2] = inf; r[2] = kNoNode; }
+                        if (!h3) { t[3] = inf; r[3] = kNoNode; }
+                        order_slots(t, r);
+                        if (r[3] != kNoNode) { st.push(sp, r[3], t[3]); sp++; }
+                        if (r[2] != kNoNode) { st.push(sp, r[2], t[2]); sp++; }
+                        if (r[1] != kNoNode) { st.push(sp, r[1], t[1]); sp++; }
+                        if (r[0] != kNoNode) cur = r[0]; else need_pop = true;
+                    } else {
                     float t0, t1, t2, t3;
                     const bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, tmin, t0) && t0 < tmax;
                     const bool h1 = r1 != kNoNode && slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t1) && t1 < tmax;
@@ -358,6 +388,7 @@ struct Traversal {
                     if (h1 && h0) { st.push(sp, r1, t1); sp++; }
                     if (h0 || h1 || h2 || h3) cur = h0 ? r0 : h1 ? r1 : h2 ? r2 : r3;
                     else need_pop = true;
+                    }
                 }
             } else if (is_node) {
                 GlobalF4 q = (GlobalF4)(nodes + cur);

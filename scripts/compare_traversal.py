@@ -1,6 +1,6 @@
 """Exact against fast traversal on one scene: mismatching first hits (ids, distances), node records per ray, Mrays/s
 of the batch query, Mpaths/s of the bounce loop.
-usage: python scripts/compare_traversal.py <cornell|heightfield|soup> [ntris width height spp depth]
+usage: python scripts/compare_traversal.py <cornell|heightfield|soup> [ntris width height spp depth two_level_records]
 Prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,7 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 spp = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 depth = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+two_level = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 
 if kind == "cornell":
     d = os.path.join(SCENES, "cornell-box-glass")
@@ -32,6 +33,7 @@ else:
     label = f"{kind} {len(objs[0]['indices']) // 3}"
 tr = cpt.Tracer(sc, W, H, max_depth=depth)
 tr.set_integrator(3)
+tr.set_node_records(two_level)
 tr.build_buffers()
 
 n = W * H
@@ -47,7 +49,7 @@ rays[:, 0:3] = o; rays[:, 3] = 1e-4; rays[:, 4:7] = dd; rays[:, 7] = np.finfo(np
 d_int = cpt.DeviceArray.from_host(rays)
 del rays, o, dd
 
-out = {"scene": label, "film": [W, H], "depth": depth}
+out = {"scene": label, "film": [W, H], "depth": depth, "two_level_records": bool(two_level)}
 for name, d_rays, count in (("camera_rays", d_cam, n), ("interior_rays", d_int, m)):
     res = {}
     hits = {}
