@@ -65,12 +65,13 @@ struct InstanceDev {
     int32_t light;       // index into the light table or -1
     uint32_t tlas_position;  // position of the instance among the sorted leaves of the top-level BVH (the reference visits leaves in descending position)
     uint32_t flags;          // kInstanceIdentity
-    uint32_t pad[3];
+    uint32_t zero_sign[3];   // kInstanceIdentity: per component of a transformed point, bits 31..29 = sign bits of the three zeros of transform_inv that meet its other terms
 };
 // transform_inv is the identity matrix up to the signs of its zeros (what the inverse of an untransformed object's matrix
-// comes out as).  Its product with a finite point or direction returns every component that is not zero unchanged,
-// and a zero as a zero of some sign, so the traversal may enter such an instance without the two matrix products
-// whenever the signs of zeros cannot matter.
+// comes out as).  Its product with a finite point p, in the evaluation order of mul(), (1*x + z1*y) + (z2*z + z3*1) for
+// the first component, returns a component that is not zero unchanged; a zero comes out negative only if it went in
+// negative and the three other terms are negative zeros too, which depends on the signs of z1, z2, z3 (zero_sign)
+// and of the other two components.  So the traversal can enter such an instance without the matrix products.
 constexpr uint32_t kInstanceIdentity = 1u;
 
 enum BsdfType : int { kLambert = 0, kPhong = 1, kBlinnPhong = 2, kMicrofacet = 3, kGlass = 4 };   // src/kernels/bsdf/bsdf.cuh:14-20

@@ -289,9 +289,19 @@ void PathTracer::BuildInstancesAndLights() {
         inst.transform_inv = InverseTransform(inst.transform);
         inst.transform_it = cpt::transpose(inst.transform_inv);
         {
-            const float *m = &inst.transform_inv.c[0].x;
+            const float *m = &inst.transform_inv.c[0].x;      // m[4 * column + row]
             bool identity = true;
             for (int k = 0; k < 16; k++) identity = identity && (k % 5 == 0 ? m[k] == 1.0f : m[k] == 0.0f);
+            // component r of the product: (m[r]*x + m[4+r]*y) + (m[8+r]*z + m[12+r]*1); the zeros next to the 1 of row r, in term order
+            for (int r = 0; r < 3; r++) {
+                uint32_t word = 0, bit = 0x80000000u;
+                for (int c = 0; c < 4; c++) {
+                    if (c == r) continue;
+                    if (std::signbit(m[4 * c + r])) word |= bit;
+                    bit >>= 1;
+                }
+                inst.zero_sign[r] = word;
+            }
             if (identity) inst.flags |= cpt::kInstanceIdentity;
         }
         inst.mesh = instance_mesh_[slot];

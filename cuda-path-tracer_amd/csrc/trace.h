@@ -131,13 +131,20 @@ struct RayFrame {
     }
 };
 
+// One component of transform_inv * (p, 1) for a transform_inv that is the identity up to the signs of its zeros: c is
+// the component, a and b the other two in the order they appear in the sum, signs the three zero signs (bits 31, 30, 29).
+__device__ inline float identity_component(float c, float a, float b, uint32_t signs) {
+    const uint32_t top = 0x80000000u;
+    const uint32_t negative = __float_as_uint(c) & (signs ^ __float_as_uint(a)) & ((signs << 1) ^ __float_as_uint(b)) & (signs << 2) & top;
+    return c == 0.0f ? __uint_as_float(negative) : c;
+}
+
 // The ray (ow, dw) of the world frame (reciprocal direction wr, fast division applicable: wfast) in the space of instance
 // `in` (AccelTop::Intersect, accel.cuh:131-133: origin and direction through the inverse transform).  Where the
 // inverse transform is the identity up to the signs of its zeros, the matrix products return every component that
-// is not zero unchanged and a zero as a zero whose sign depends on the matrix.  A direction the fast division
-// applies to has no zero, so it and its reciprocals are the world frame's; the origin is too unless one of its
-// components is zero, and then only its product is evaluated.  The ordered traversal makes no promise about signs
-// of zeros and keeps the world frame for every ray.
+// is not zero unchanged and a zero as a zero whose sign follows from the signs involved.  A direction the fast division
+// applies to has no zero, so it and its reciprocals are the world frame's; the origin's zeros get their signs from
+// identity_component.  The ordered traversal makes no promise about signs of zeros and keeps the world frame as it is.
 template <bool FAST>
 __device__ inline void enter_instance(RayFrame &f, const InstanceDev &in, V3 ow, V3 dw, V3 wr, bool wfast, bool boxes_ok) {
     if ((in.flags & kInstanceIdentity) != 0u && (FAST || wfast)) {
@@ -146,7 +153,9 @@ __device__ inline void enter_instance(RayFrame &f, const InstanceDev &in, V3 ow,
         f.r = wr;
         f.fast = FAST ? true : boxes_ok;
         if constexpr (!FAST) {
-            if (ow.x == 0.0f || ow.y == 0.0f || ow.z == 0.0f) f.o = xyz(mul(in.transform_inv, v4(ow, 1.0f)));
+            // first component: (1*x + z*y) + (z*z' + z*1); second: (z*x + 1*y) + ...; third: (z*x + z*y) + (1*z + z*1)
+            f.o = v3(identity_component(ow.x, ow.y, ow.z, in.zero_sign[0]), identity_component(ow.y, ow.x, ow.z, in.zero_sign[1]),
+                     identity_component(ow.z, ow.x, ow.y, in.zero_sign[2]));
         }
     } else {
         const M4 inv = in.transform_inv;
