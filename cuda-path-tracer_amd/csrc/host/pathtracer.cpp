@@ -108,6 +108,7 @@ void PathTracer::BuildAccel() {
     largest_mesh_ = (size_t)-1;
     uint32_t largest = 0;
 
+    const bool wide = node_records_ != 0;
     std::vector<cpt::Bbox> leaf_bboxes;
     scene_.ForEach<MeshComponent, const MaterialComponent>([&](SceneObject &object, MeshComponent &mesh_comp, const MaterialComponent &) {
         Mesh *mesh = mesh_comp.GetMesh();
@@ -145,8 +146,14 @@ void PathTracer::BuildAccel() {
             if (timed) CPT_HIP(hipEventRecord(box_ev[1], stream_));
             bool profile = timed;
             float stage[5];
+            mb->root.Allocate(sizeof(cpt::AccelRoot));
+            if (wide) mb->wide_nodes.Allocate(sizeof(cpt::PackedNode) * 2 * (n > 1 ? n - 1 : 1));
+            cpt::RecordOutputs records;
+            records.binary = mb->packed_nodes.TypedGpuData<cpt::PackedNode>();
+            records.wide = wide ? mb->wide_nodes.TypedGpuData<cpt::PackedNode>() : nullptr;
+            records.root = mb->root.TypedGpuData<cpt::AccelRoot>();
             rc_check(cpt::lbvh_build(mb->nodes.TypedGpuData<cpt::AccelNode>(), mb->bboxes.TypedGpuData<cpt::Bbox>(), merged, n, stream_, &workspace_,
-                                     leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->keys.TypedGpuData<uint64_t>(), nullptr, profile ? stage : nullptr),
+                                     leaf_scratch_.TypedGpuData<cpt::Bbox>(), mb->keys.TypedGpuData<uint64_t>(), nullptr, profile ? stage : nullptr, &records),
                      "bottom-level build");
             if (profile) {
                 memcpy(build_stage_ms_, stage, sizeof(stage));
@@ -169,8 +176,7 @@ void PathTracer::BuildAccel() {
     uint32_t num_instances = (uint32_t)instance_mesh_.size();
     if (num_instances == 0) return;
 
-    const bool wide = node_records_ != 0;
-    // mesh descriptor table; the pack kernels fill in each root afterwards
+    // mesh descriptor table; each root record is copied in from where its build left it
     std::vector<cpt::MeshDev> mesh_table(meshes_.size());
     for (size_t i = 0; i < meshes_.size(); i++) {
         MeshBuffers &mb = *meshes_[i];
@@ -183,10 +189,7 @@ void PathTracer::BuildAccel() {
         d.normals = mb.normals.TypedGpuData<V3>();
         d.texcoords = mb.texcoords.TypedGpuData<cpt::V2>();
         d.num_triangles = mb.num_triangles;
-        if (wide) {
-            mb.wide_nodes.Allocate(sizeof(cpt::PackedNode) * 2 * (mb.num_triangles > 1 ? mb.num_triangles - 1 : 1));
-            d.wide = mb.wide_nodes.TypedGpuData<cpt::PackedNode>();
-        }
+        if (wide) d.wide = mb.wide_nodes.TypedGpuData<cpt::PackedNode>();
     }
     mesh_table_.Allocate(sizeof(cpt::MeshDev) * mesh_table.size(), mesh_table.data(), stream_);
     for (size_t i = 0; i < meshes_.size(); i++) {
@@ -207,11 +210,9 @@ void PathTracer::BuildAccel() {
                 (void)hipEventDestroy(ev[1]);
             }
         } pack_timer{pack_ev, stream_, &pack_ms_, timed};
-        rc_check(cpt::lbvh_pack(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.tris.TypedGpuData<cpt::TriRecord>(), root,
-                                mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), mb.num_triangles,
-                                mb.indices.TypedGpuData<uint32_t>(), mb.positions.TypedGpuData<V3>(), stream_), "pack bottom level");
-        if (wide) rc_check(cpt::lbvh_pack_wide(mb.wide_nodes.TypedGpuData<cpt::PackedNode>(), mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.num_triangles, stream_),
-                           "pack bottom level, two-level records");
+        CPT_HIP(hipMemcpyAsync(root, mb.root.GpuData(), sizeof(cpt::AccelRoot), hipMemcpyDeviceToDevice, stream_));
+        rc_check(cpt::lbvh_pack_triangles(mb.tris.TypedGpuData<cpt::TriRecord>(), mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.indices.TypedGpuData<uint32_t>(),
+                                          mb.positions.TypedGpuData<V3>(), mb.num_triangles, stream_), "triangle records");
     }
 
     // top level (pathtracer.cpp:120-154)
@@ -231,21 +232,16 @@ void PathTracer::BuildAccel() {
     top_keys_.Allocate(sizeof(uint64_t) * num_instances);
     top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
     top_root_.Allocate(sizeof(cpt::AccelRoot));
+    if (wide) top_wide_.Allocate(sizeof(cpt::PackedNode) * 2 * (num_instances > 1 ? num_instances - 1 : 1));
+    cpt::RecordOutputs top_records;
+    top_records.binary = top_packed_.TypedGpuData<cpt::PackedNode>();
+    top_records.wide = wide ? top_wide_.TypedGpuData<cpt::PackedNode>() : nullptr;
+    top_records.root = top_root_.TypedGpuData<cpt::AccelRoot>();
+    top_records.top_level = 1;
     rc_check(cpt::lbvh_build(top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), merged, num_instances, stream_, &workspace_,
-                             nullptr, top_keys_.TypedGpuData<uint64_t>(), nullptr, nullptr), "top-level build");
-    rc_check(cpt::lbvh_pack(top_packed_.TypedGpuData<cpt::PackedNode>(), nullptr, top_root_.TypedGpuData<cpt::AccelRoot>(),
-                            top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), num_instances, nullptr, nullptr, stream_),
-             "pack top level");
-
-    scene_dev_.top_wide = nullptr;
-    scene_dev_.wide_nodes = 0;
-    if (wide) {
-        top_wide_.Allocate(sizeof(cpt::PackedNode) * 2 * (num_instances > 1 ? num_instances - 1 : 1));
-        rc_check(cpt::lbvh_pack_wide(top_wide_.TypedGpuData<cpt::PackedNode>(), top_packed_.TypedGpuData<cpt::PackedNode>(), num_instances, stream_),
-                 "pack top level, two-level records");
-        scene_dev_.top_wide = top_wide_.TypedGpuData<cpt::PackedNode>();
-        scene_dev_.wide_nodes = 1;
-    }
+                             nullptr, top_keys_.TypedGpuData<uint64_t>(), nullptr, nullptr, &top_records), "top-level build");
+    scene_dev_.top_wide = wide ? top_wide_.TypedGpuData<cpt::PackedNode>() : nullptr;
+    scene_dev_.wide_nodes = wide ? 1 : 0;
     scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
     scene_dev_.top_root = top_root_.TypedGpuData<cpt::AccelRoot>();
     scene_dev_.meshes = mesh_table_.TypedGpuData<cpt::MeshDev>();

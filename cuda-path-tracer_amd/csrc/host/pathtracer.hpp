@@ -107,6 +107,7 @@ private:
         cpt::HipBuffer nodes, bboxes, keys;          // reference-layout build output
         cpt::HipBuffer packed_nodes, tris;           // traversal records
         cpt::HipBuffer wide_nodes;                   // two-level records, when built
+        cpt::HipBuffer root;                         // the build leaves the root record here
         uint32_t num_triangles = 0;
     };
 

@@ -22,6 +22,17 @@ struct BuildWorkspace {
     void release();
 };
 
+// Traversal records a build may write next to the reference-format arrays (all device pointers): the 64-byte binary
+// records (n - 1, required), the 128-byte two-level records (two PackedNode per internal node; null: not wanted) and
+// the root record.  top_level: leaves are instances (references carry the primitive id) instead of triangles
+// (references carry the sorted-leaf position).
+struct RecordOutputs {
+    PackedNode *binary = nullptr;
+    PackedNode *wide = nullptr;
+    AccelRoot *root = nullptr;
+    int top_level = 0;
+};
+
 // Drop-in for kernel::BuildAccel (src/kernels/accel/accel_build.cuh:7): `nodes` and `bboxes` are
 // device arrays of 2n-1 entries; the leaf boxes occupy bboxes[n-1 .. 2n-2] on entry and are
 // reordered in place; every node and every internal box is written.
@@ -31,10 +42,12 @@ struct BuildWorkspace {
 //               when given, bboxes[n-1..] need not be filled and one device copy is saved
 //   keys_out    optional device array of n sorted 64-bit keys (code << 32 | primitive)
 //   parents_out optional device array of 2n-1 parent indices (entry 0 is never written)
-//   stage_ms    optional host array of 5 floats: morton, sort, hierarchy pass one (leaf gather + everything inside a workgroup's leaves), hierarchy pass two (nodes spanning workgroups), 0 (forces a sync)
+//   stage_ms    optional host array of 5 floats: morton, sort, hierarchy pass one (leaf gather + everything inside a workgroup's leaves), hierarchy pass two (nodes spanning workgroups) with the records of those nodes, 0 (forces a sync)
+//   records     optional traversal records, written by the hierarchy passes themselves (a node finished inside a
+//               workgroup has its children and grandchildren in LDS at that moment) and a short kernel for the rest
 // Returns 0 or a hipError_t value.
 int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t num_primitives, hipStream_t stream, BuildWorkspace *ws,
-               const Bbox *leaf_src, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms);
+               const Bbox *leaf_src, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms, const RecordOutputs *records = nullptr);
 
 // The same build (in place, leaf boxes pre-filled, returns when it has finished) with all scratch in a device
 // array of fixed size inside the library: no allocation of any kind.  At most kStaticMaxPrimitives primitives
@@ -46,14 +59,7 @@ int lbvh_build_static(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32
 // Leaf boxes of a triangle mesh (w = 1), the device counterpart of src/scene/mesh.cpp:88-98.
 int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);
 
-// Packs a finished build into 64-byte traversal records.  out_tris == nullptr selects the top
-// level (leaf references carry instance ids); otherwise triangle records are written in sorted
-// leaf order.  `root` is a device pointer.
-int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const AccelNode *nodes, const Bbox *bboxes, uint32_t num_primitives,
-              const uint32_t *indices, const V3 *positions, hipStream_t stream);
-
-// Two-level records (two PackedNode per internal node: the right child's half, then the left child's) from the binary
-// records lbvh_pack wrote; nothing to do for a single primitive.
-int lbvh_pack_wide(PackedNode *out_wide, const PackedNode *packed_nodes, uint32_t num_primitives, hipStream_t stream);
+// 48-byte triangle records in sorted-leaf order from a finished bottom-level build.
+int lbvh_pack_triangles(TriRecord *out_tris, const AccelNode *nodes, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);
 
 }  // namespace cpt

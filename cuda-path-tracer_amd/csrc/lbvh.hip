@@ -736,9 +736,44 @@ __global__ void __launch_bounds__(kBlock) k_climb(const Carrier *__restrict__ ca
 // beyond that child's far end plus one, bits 0-15 = the far end as a leaf position of the workgroup.
 constexpr uint32_t kSlotGlobal = 0x40000000u;       // initial word of a split whose parent spans several workgroups
 
-template <bool PARENTS, int BLOCK>
+// ---- packing into traversal records --------------------------------------------------------
+// The traversal may replace its divisions by a reciprocal-based sequence that is exact only while
+// every box coordinate is zero or of magnitude in [2^-50, 2^50]; one flag per BVH records that.
+__device__ inline bool coord_in_fast_range(float x) {
+    float a = fabsf(x);
+    return x == 0.0f || (a >= 0x1p-50f && a <= 0x1p50f);
+}
+__device__ inline bool box_in_fast_range(const Bbox &b) {
+    return coord_in_fast_range(b.pmin.x) && coord_in_fast_range(b.pmin.y) && coord_in_fast_range(b.pmin.z) && coord_in_fast_range(b.pmax.x) &&
+           coord_in_fast_range(b.pmax.y) && coord_in_fast_range(b.pmax.z);
+}
+
+__device__ inline uint32_t child_ref(uint32_t child, const AccelNode *nodes, uint32_t n, int top_level) {
+    if (child < n - 1) return child;
+    return kLeafBit | (top_level ? nodes[child].lc_or_id : child - (n - 1));
+}
+
+constexpr uint32_t kNoChild = 0xffffffffu;       // reference of an empty slot of a two-level record
+
+// Traversal records straight from the hierarchy pass: a node finished inside a workgroup has its children and their
+// children in LDS at that moment, so its 64-byte binary record and its 128-byte two-level record (see pack_wide_global
+// for the layout) are written then, without reading anything back; local_mask gets one bit per internal node that was
+// served this way, and k_pack_rest makes the records of the others (the nodes that span workgroups) from memory.
+__device__ inline void store_half(float4 *o, const float a[6], uint32_t ra, const float b[6], uint32_t rb) {
+    o[0] = make_float4(a[0], a[1], a[2], a[3]);
+    o[1] = make_float4(a[4], a[5], b[0], b[1]);
+    o[2] = make_float4(b[2], b[3], b[4], b[5]);
+    o[3] = make_float4(__uint_as_float(ra), __uint_as_float(rb), 0.0f, 0.0f);
+}
+__device__ inline bool six_in_fast_range(const float b[6]) {
+    return coord_in_fast_range(b[0]) && coord_in_fast_range(b[1]) && coord_in_fast_range(b[2]) && coord_in_fast_range(b[3]) && coord_in_fast_range(b[4]) &&
+           coord_in_fast_range(b[5]);
+}
+
+template <bool PARENTS, int BLOCK, bool RECORDS>
 __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__ keys, const Bbox *__restrict__ leaf_src, Bbox *bboxes, AccelNode *nodes,
-                                                    uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, uint32_t carrier_limit, Bbox merged, uint32_t n) {
+                                                    uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, uint32_t carrier_limit, Bbox merged, uint32_t n,
+                                                    RecordOutputs rec, unsigned long long *local_mask) {
     __shared__ Carrier s_park[kCarriersPerGroup];
     __shared__ uint32_t s_park_count;
     __shared__ uint64_t s_key[BLOCK + 2];        // keys b0-1 .. b1+1
@@ -874,6 +909,44 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
             gb[1] = make_float4(key_to_float(max(init_hi[0], a.w)), key_to_float(max(init_hi[1], b.x)), key_to_float(max(init_hi[2], b.y)), merged.pmin.w);
         }
     }
+    if constexpr (RECORDS) {
+        const uint4 own = s_node[t][1];
+        const bool finished = own.w != 0u;
+        const unsigned long long served = __ballot(finished);
+        if (lane == 0) local_mask[(b0 + t) >> 6] = served;
+        if (finished) {
+            // entry e as a traversal slot: box as floats (an internal node's folded with the box every internal box starts from), reference
+            auto slot_of = [&](uint32_t e, float box[6]) -> uint32_t {
+                const uint4 a = s_node[e][0], b = s_node[e][1];
+                if (e < (uint32_t)BLOCK) {
+                    box[0] = key_to_float(min(init_lo[0], a.x)); box[1] = key_to_float(min(init_lo[1], a.y)); box[2] = key_to_float(min(init_lo[2], a.z));
+                    box[3] = key_to_float(max(init_hi[0], a.w)); box[4] = key_to_float(max(init_hi[1], b.x)); box[5] = key_to_float(max(init_hi[2], b.y));
+                    return b0 + e;
+                }
+                box[0] = key_to_float(a.x); box[1] = key_to_float(a.y); box[2] = key_to_float(a.z);
+                box[3] = key_to_float(a.w); box[4] = key_to_float(b.x); box[5] = key_to_float(b.y);
+                const uint32_t leaf = e - BLOCK;
+                return kLeafBit | (rec.top_level ? (uint32_t)s_key[leaf + 1] : b0 + leaf);
+            };
+            const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float lbox[6], rbox[6];
+            const uint32_t lref = slot_of(own.z, lbox), rref = slot_of(own.w, rbox);
+            if (!six_in_fast_range(lbox) || !six_in_fast_range(rbox)) atomicOr(&rec.root->flags, 1u);
+            store_half(reinterpret_cast<float4 *>(rec.binary + (b0 + t)), lbox, lref, rbox, rref);
+            if (rec.wide) {
+                float4 *o = reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)(b0 + t));
+                auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) {
+                    if (child >= (uint32_t)BLOCK) { store_half(h, cbox, cref, none, kNoChild); return; }
+                    const uint4 c = s_node[child][1];
+                    float first[6], second[6];
+                    const uint32_t second_ref = slot_of(c.z, second), first_ref = slot_of(c.w, first);      // right child first
+                    store_half(h, first, first_ref, second, second_ref);
+                };
+                half(own.w, rbox, rref, o);
+                half(own.z, lbox, lref, o + 4);
+            }
+        }
+    }
     const uint32_t parked = min(s_park_count, carrier_limit);
     if (t < parked) carriers[(size_t)blockIdx.x * kCarriersPerGroup + t] = s_park[t];
     if (t == 0) carrier_counts[blockIdx.x] = parked;
@@ -889,86 +962,54 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
     }
 }
 
-// ---- packing into traversal records --------------------------------------------------------
-// The traversal may replace its divisions by a reciprocal-based sequence that is exact only while
-// every box coordinate is zero or of magnitude in [2^-50, 2^50]; one flag per BVH records that.
-__device__ inline bool coord_in_fast_range(float x) {
-    float a = fabsf(x);
-    return x == 0.0f || (a >= 0x1p-50f && a <= 0x1p50f);
+// Records of one internal node from the finished arrays in memory.  Binary: both children's boxes and references.
+// Two-level: two halves in the same layout, the first for the right child, the second for the left child; a half holds
+// the child itself when the child is a leaf (second slot empty: reference kNoChild), otherwise the child's two
+// children, right one first, so that the four slots are in the order the reference's traversal (right child first,
+// accel.cuh:84-91) reaches them.
+__device__ inline void box6(const Bbox &b, float out[6]) {
+    out[0] = b.pmin.x; out[1] = b.pmin.y; out[2] = b.pmin.z; out[3] = b.pmax.x; out[4] = b.pmax.y; out[5] = b.pmax.z;
 }
-__device__ inline bool box_in_fast_range(const Bbox &b) {
-    return coord_in_fast_range(b.pmin.x) && coord_in_fast_range(b.pmin.y) && coord_in_fast_range(b.pmin.z) && coord_in_fast_range(b.pmax.x) &&
-           coord_in_fast_range(b.pmax.y) && coord_in_fast_range(b.pmax.z);
+__device__ inline void pack_from_memory(uint32_t i, const RecordOutputs &rec, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes, uint32_t n) {
+    const AccelNode nd = nodes[i];
+    float lbox[6], rbox[6];
+    box6(bboxes[nd.lc_or_id], lbox);
+    box6(bboxes[nd.rc], rbox);
+    if (!six_in_fast_range(lbox) || !six_in_fast_range(rbox)) atomicOr(&rec.root->flags, 1u);
+    const uint32_t lref = child_ref(nd.lc_or_id, nodes, n, rec.top_level), rref = child_ref(nd.rc, nodes, n, rec.top_level);
+    store_half(reinterpret_cast<float4 *>(rec.binary + i), lbox, lref, rbox, rref);
+    if (!rec.wide) return;
+    const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) {
+        if (child >= n - 1) { store_half(h, cbox, cref, none, kNoChild); return; }
+        const AccelNode c = nodes[child];
+        float first[6], second[6];
+        box6(bboxes[c.rc], first);
+        box6(bboxes[c.lc_or_id], second);
+        store_half(h, first, child_ref(c.rc, nodes, n, rec.top_level), second, child_ref(c.lc_or_id, nodes, n, rec.top_level));
+    };
+    float4 *o = reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)i);
+    half(nd.rc, rbox, rref, o);
+    half(nd.lc_or_id, lbox, lref, o + 4);
 }
 
-__device__ inline uint32_t child_ref(uint32_t child, const AccelNode *nodes, uint32_t n, int top_level) {
-    if (child < n - 1) return child;
-    return kLeafBit | (top_level ? nodes[child].lc_or_id : child - (n - 1));
-}
-
-__global__ void __launch_bounds__(kBlock) k_pack_nodes(PackedNode *__restrict__ out, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes,
-                                                        uint32_t n, int top_level, AccelRoot *__restrict__ root) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    // root->flags was zeroed by the host before this launch; lanes only ever OR bits into it
+// The root record of a BVH, and the records of the internal nodes the hierarchy pass did not serve (local_mask null:
+// of all of them).  root->flags was zeroed before the build; lanes only ever OR bits into it.
+__global__ void __launch_bounds__(kBlock) k_pack_rest(RecordOutputs rec, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes, uint32_t n,
+                                                       const unsigned long long *__restrict__ local_mask) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
-        Bbox b = bboxes[0];
+        const Bbox b = bboxes[0];
+        AccelRoot *root = rec.root;
         root->bmin[0] = b.pmin.x; root->bmin[1] = b.pmin.y; root->bmin[2] = b.pmin.z;
         root->bmax[0] = b.pmax.x; root->bmax[1] = b.pmax.y; root->bmax[2] = b.pmax.z;
-        root->ref = n == 1 ? (kLeafBit | (top_level ? nodes[0].lc_or_id : 0u)) : 0u;
+        root->ref = n == 1 ? (kLeafBit | (rec.top_level ? nodes[0].lc_or_id : 0u)) : 0u;
         root->num_prims = n;
         if (!box_in_fast_range(b)) atomicOr(&root->flags, 1u);
     }
     if (n < 2 || i >= n - 1) return;
-    AccelNode nd = nodes[i];
-    Bbox l = bboxes[nd.lc_or_id], r = bboxes[nd.rc];
-    if (!box_in_fast_range(l) || !box_in_fast_range(r)) atomicOr(&root->flags, 1u);
-    float4 q0 = make_float4(l.pmin.x, l.pmin.y, l.pmin.z, l.pmax.x);
-    float4 q1 = make_float4(l.pmax.y, l.pmax.z, r.pmin.x, r.pmin.y);
-    float4 q2 = make_float4(r.pmin.z, r.pmax.x, r.pmax.y, r.pmax.z);
-    uint32_t lref = child_ref(nd.lc_or_id, nodes, n, top_level), rref = child_ref(nd.rc, nodes, n, top_level);
-    float4 q3 = make_float4(__uint_as_float(lref), __uint_as_float(rref), 0.0f, 0.0f);
-    float4 *o = reinterpret_cast<float4 *>(out + i);
-    o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
-}
-
-// Two levels of the tree per record: internal node i becomes two 64-byte halves in the layout of PackedNode, the first
-// for its right child, the second for its left child.  A half holds the child itself when the child is a leaf (second
-// slot empty: reference kNoChild), otherwise the child's two children, right one first.  The four slots are in the
-// order the reference's traversal (right child first, accel.cuh:84-91) reaches them.  Made from the binary records:
-// node i's own record has its children's boxes, a child's record has the grandchildren's (three 64-byte reads, the
-// children's mostly from lines a neighbouring lane reads too).
-constexpr uint32_t kNoChild = 0xffffffffu;
-__global__ void __launch_bounds__(kBlock) k_pack_wide(PackedNode *__restrict__ out, const PackedNode *__restrict__ packed, uint32_t n) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (n < 2 || i >= n - 1) return;
-    const float4 *own = reinterpret_cast<const float4 *>(packed + i);
-    const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
-    const uint32_t lref = __float_as_uint(p3.x), rref = __float_as_uint(p3.y);
-    float4 *o = reinterpret_cast<float4 *>(out + 2 * (size_t)i);
-    auto half_of_internal = [&](uint32_t c, float4 *h) {     // the child's record with its two slots swapped
-        const float4 *q = reinterpret_cast<const float4 *>(packed + c);
-        const float4 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
-        h[0] = make_float4(c1.z, c1.w, c2.x, c2.y);
-        h[1] = make_float4(c2.z, c2.w, c0.x, c0.y);
-        h[2] = make_float4(c0.z, c0.w, c1.x, c1.y);
-        h[3] = make_float4(c3.y, c3.x, 0.0f, 0.0f);
-    };
-    if (rref & kLeafBit) {
-        o[0] = make_float4(p1.z, p1.w, p2.x, p2.y);
-        o[1] = make_float4(p2.z, p2.w, 0.0f, 0.0f);
-        o[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        o[3] = make_float4(__uint_as_float(rref), __uint_as_float(kNoChild), 0.0f, 0.0f);
-    } else {
-        half_of_internal(rref, o);
-    }
-    if (lref & kLeafBit) {
-        o[4] = make_float4(p0.x, p0.y, p0.z, p0.w);
-        o[5] = make_float4(p1.x, p1.y, 0.0f, 0.0f);
-        o[6] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        o[7] = make_float4(__uint_as_float(lref), __uint_as_float(kNoChild), 0.0f, 0.0f);
-    } else {
-        half_of_internal(lref, o + 4);
-    }
+    if (local_mask && ((local_mask[i >> 6] >> (i & 63u)) & 1ull)) return;
+    pack_from_memory(i, rec, nodes, bboxes, n);
 }
 
 __global__ void __launch_bounds__(kBlock) k_pack_tris(TriRecord *__restrict__ out, const AccelNode *__restrict__ nodes, const uint32_t *__restrict__ indices,
@@ -1010,6 +1051,7 @@ size_t BuildWorkspace::bytes_for(uint32_t n) {
          + up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock))   // carriers between the two hierarchy passes
          + up(4 * (size_t)cdiv(n, kUpBlock))   // their counts
          + up(4 * (size_t)n)                   // one exchange word per split
+         + up(8 * ((size_t)cdiv(n, 64) + 1))   // one bit per internal node: its records were written by the first hierarchy pass
          + up(4 * ((size_t)kPasses * kBins + 64 + (size_t)kPasses * tiles * kBins));   // digit histograms, tile tickets, look-back words
 }
 
@@ -1030,8 +1072,9 @@ void BuildWorkspace::release() {
 }
 
 int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, hipStream_t stream, BuildWorkspace *ws_in,
-               const Bbox *leaf_src_in, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms) {
+               const Bbox *leaf_src_in, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms, const RecordOutputs *records) {
     if (n == 0) return 0;
+    if (records && (!records->binary || !records->root)) return (int)hipErrorInvalidValue;
     BuildWorkspace local;
     BuildWorkspace *ws = ws_in ? ws_in : &local;
     int rc = ws->reserve(n);
@@ -1045,6 +1088,7 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     Carrier *carriers = reinterpret_cast<Carrier *>(p); p += up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock));
     uint32_t *carrier_counts = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)cdiv(n, kUpBlock));
     uint32_t *slots = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)n);
+    unsigned long long *local_mask = reinterpret_cast<unsigned long long *>(p); p += up(8 * ((size_t)cdiv(n, 64) + 1));
     uint32_t *digit_hist = reinterpret_cast<uint32_t *>(p);            // kPasses x kBins, then first positions
     uint32_t *tickets = digit_hist + kPasses * kBins;                  // one per pass
     uint32_t *tile_status = tickets + 64;                              // kPasses x tiles x kBins
@@ -1109,22 +1153,31 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
         const uint32_t groups = cdiv(n, kUpBlock);
         const uint32_t carrier_limit = ws->carrier_limit < kCarriersPerGroup ? ws->carrier_limit : kCarriersPerGroup;
         if (!slots_cleared) HIP_OK(hipMemsetAsync(slots, 0, 4 * (size_t)(n - 1), stream));      // one exchange word per split
+        const RecordOutputs rec = records ? *records : RecordOutputs{};
+        if (records) HIP_OK(hipMemsetAsync(rec.root, 0, sizeof(AccelRoot), stream));
+        auto first_pass = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers, carrier_counts,
+                               carrier_limit, merged, n, rec, local_mask);
+        };
         if (parents_out) {
-            hipLaunchKernelGGL((k_build_up<true, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers,
-                               carrier_counts, carrier_limit, merged, n);
+            if (records) first_pass(k_build_up<true, kUpBlock, true>); else first_pass(k_build_up<true, kUpBlock, false>);
             mark(3);
             hipLaunchKernelGGL(k_climb<true>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, parents_out, slots, merged, n);
         } else {
-            hipLaunchKernelGGL((k_build_up<false, kUpBlock>), dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, (uint32_t *)nullptr, slots,
-                               carriers, carrier_counts, carrier_limit, merged, n);
+            if (records) first_pass(k_build_up<false, kUpBlock, true>); else first_pass(k_build_up<false, kUpBlock, false>);
             mark(3);
             hipLaunchKernelGGL(k_climb<false>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, (uint32_t *)nullptr, slots, merged, n);
         }
+        if (records) hipLaunchKernelGGL(k_pack_rest, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, rec, nodes, bboxes, n, local_mask);
     } else {
         hipLaunchKernelGGL(k_gather_leaves, dim3(grid_n), dim3(kBlock), 0, stream, src, leaf_src, bboxes, nodes, n);
         mark(3);
+        if (records) {
+            HIP_OK(hipMemsetAsync(records->root, 0, sizeof(AccelRoot), stream));
+            hipLaunchKernelGGL(k_pack_rest, dim3(1), dim3(kBlock), 0, stream, *records, nodes, bboxes, n, (const unsigned long long *)nullptr);
+        }
     }
     mark(4);
     mark(5);
@@ -1193,19 +1246,9 @@ int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions
     return (int)hipGetLastError();
 }
 
-int lbvh_pack(PackedNode *out_nodes, TriRecord *out_tris, AccelRoot *root, const AccelNode *nodes, const Bbox *bboxes, uint32_t n,
-              const uint32_t *indices, const V3 *positions, hipStream_t stream) {
+int lbvh_pack_triangles(TriRecord *out_tris, const AccelNode *nodes, const uint32_t *indices, const V3 *positions, uint32_t n, hipStream_t stream) {
     if (n == 0) return 0;
-    int top_level = out_tris == nullptr;
-    HIP_OK(hipMemsetAsync(root, 0, sizeof(AccelRoot), stream));
-    hipLaunchKernelGGL(k_pack_nodes, dim3(cdiv(n > 1 ? n - 1 : 1, kBlock)), dim3(kBlock), 0, stream, out_nodes, nodes, bboxes, n, top_level, root);
-    if (!top_level) hipLaunchKernelGGL(k_pack_tris, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, out_tris, nodes, indices, positions, n);
-    return (int)hipGetLastError();
-}
-
-int lbvh_pack_wide(PackedNode *out_wide, const PackedNode *packed, uint32_t n, hipStream_t stream) {
-    if (n < 2) return 0;
-    hipLaunchKernelGGL(k_pack_wide, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, out_wide, packed, n);
+    hipLaunchKernelGGL(k_pack_tris, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, out_tris, nodes, indices, positions, n);
     return (int)hipGetLastError();
 }
 
