@@ -134,36 +134,50 @@ struct Flow {
                 }
             }
         } else if (ct >= ci) {
+            // A lane at a triangle goes on to the next pending entry when that is a triangle of the same mesh too
+            // (the leaves under one two-level record), up to kLeafRun tests in one trip: its own order of tests and
+            // pops is unchanged, and it does not wait for the vote between them.  On binary records one test per trip.
             if (is_tri) {
-                float t, bv, bw;
-                uint32_t prim;
-                cnt.tris++;
-                need_pop = true;
-                if constexpr (FAST) {
-                    bool tie;
-                    const uint32_t slot = cur & ~kLeafBit;
-                    if (tri_test_or_tie(tris + slot, f.o, f.d, kRayTMin, tmax, t, bv, bw, prim, tie)) {
-                        if (any) {
-                            if (!tie) { found = true; need_pop = false; cur = kNoNode; }       // any hit is strictly inside the reach (accel.cuh:96-110)
-                        } else {
-                            const bool later = inst_pos > hit_pos || (inst_pos == hit_pos && slot > hit_slot);
-                            if (!tie || !found || later) {
-                                found = true;
-                                tmax = t;
-                                hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
-                                hit_pos = inst_pos; hit_slot = slot;
+                for (int run = 0; run < (WIDE ? kLeafRun : 1); run++) {
+                    float t, bv, bw;
+                    uint32_t prim;
+                    cnt.tris++;
+                    bool ended = false;
+                    if constexpr (FAST) {
+                        bool tie;
+                        const uint32_t slot = cur & ~kLeafBit;
+                        if (tri_test_or_tie(tris + slot, f.o, f.d, kRayTMin, tmax, t, bv, bw, prim, tie)) {
+                            if (any) {
+                                if (!tie) { found = true; ended = true; }       // any hit is strictly inside the reach (accel.cuh:96-110)
+                            } else {
+                                const bool later = inst_pos > hit_pos || (inst_pos == hit_pos && slot > hit_slot);
+                                if (!tie || !found || later) {
+                                    found = true;
+                                    tmax = t;
+                                    hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                                    hit_pos = inst_pos; hit_slot = slot;
+                                }
                             }
                         }
+                    } else if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
+                        found = true;
+                        if (any) {
+                            ended = true;
+                        } else {
+                            tmax = t;
+                            hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                        }
                     }
-                } else if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
-                    found = true;
-                    if (any) {
-                        need_pop = false;
-                        cur = kNoNode;
-                    } else {
-                        tmax = t;
-                        hit.inst = inst_id; hit.prim = prim; hit.u = bv; hit.v = bw;
+                    cur = kNoNode;
+                    if (ended) break;
+                    // the next pending entry of this mesh that is still within reach
+                    while (sp != sp_base) {
+                        --sp;
+                        const uint2 e = st.at(sp);
+                        if (within_reach<FAST>(__uint_as_float(e.y), tmax, any)) { cur = e.x; break; }
                     }
+                    if (cur == kNoNode) { need_pop = true; break; }       // the mesh is done: leave it below
+                    if (!(cur & kLeafBit)) break;
                 }
             }
         } else {
