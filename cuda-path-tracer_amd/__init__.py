@@ -53,6 +53,7 @@ _sig("cpt_builder_destroy", None, [_vp])
 _sig("cpt_builder_set_sort", C.c_int, [_vp, C.c_int])
 _sig("cpt_builder_set_carrier_limit", C.c_int, [_vp, C.c_uint32])
 _sig("cpt_builder_build", C.c_int, [_vp, _vp, _vp, _vp, _f32, C.c_uint32, _vp, _vp])
+_sig("cpt_builder_build_records", C.c_int, [_vp, _vp, _vp, _vp, _f32, C.c_uint32, C.c_int, _vp, _vp, _vp])
 _sig("cpt_scene_create", _vp, [])
 _sig("cpt_scene_destroy", None, [_vp])
 _sig("cpt_scene_load_obj", C.c_int, [_vp, C.c_char_p, C.c_int])

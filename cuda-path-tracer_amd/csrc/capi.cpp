@@ -185,6 +185,21 @@ int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void 
     return CPT_OK;
 }
 
+int cpt_builder_build_records(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8], uint32_t num_primitives,
+                              int top_level, void *d_binary_records, void *d_two_level_records, void *d_root_record) {
+    if (!b || !d_nodes || !d_bboxes || !merged_bbox || !d_binary_records || !d_root_record) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: null argument");
+    if (num_primitives == 0) return CPT_OK;
+    if (num_primitives > 0x7fffffffu) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: more than 2^31-1 primitives");
+    cpt::RecordOutputs records;
+    records.binary = static_cast<cpt::PackedNode *>(d_binary_records);
+    records.wide = static_cast<cpt::PackedNode *>(d_two_level_records);
+    records.root = static_cast<cpt::AccelRoot *>(d_root_record);
+    records.top_level = top_level ? 1 : 0;
+    int rc = cpt::lbvh_build(static_cast<cpt::AccelNode *>(d_nodes), static_cast<cpt::Bbox *>(d_bboxes), MakeBox(merged_bbox), num_primitives, nullptr,
+                             &b->ws, static_cast<const cpt::Bbox *>(d_leaf_boxes), nullptr, nullptr, nullptr, &records);
+    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "lbvh_build");
+}
+
 // ------------------------------------------------------------------ scene
 cpt_scene *cpt_scene_create(void) { return new cpt_scene(); }
 void cpt_scene_destroy(cpt_scene *s) { delete s; }

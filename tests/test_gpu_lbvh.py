@@ -198,3 +198,72 @@ def test_reusable_builder_is_deterministic(cpt):
     cpt.lib.cpt_builder_destroy(b)
     o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
     assert np.array_equal(first[0], o_nodes) and np.array_equal(first[1], o_boxes.view(np.uint32))
+
+
+def records_from_arrays(nodes, boxes, n, top_level):
+    """The traversal records of a finished tree, restated with numpy from the reference-format arrays: binary records
+    (children's boxes and references), two-level records (the grandchildren in the reference's visit order, a leaf child
+    standing for itself) and the root record."""
+    LEAF, NONE = np.uint32(0x80000000), np.uint32(0xFFFFFFFF)
+    ids = np.arange(2 * n - 1, dtype=np.uint32)
+    leaf_ref = LEAF | (nodes[:, 0] if top_level else ids - np.uint32(n - 1))
+    ref = np.where(ids >= n - 1, leaf_ref, ids).astype(np.uint32)
+    box6 = boxes[:, [0, 1, 2, 4, 5, 6]].view(np.uint32)                     # min.xyz, max.xyz
+    lc, rc = nodes[: n - 1, 0], nodes[: n - 1, 1]
+
+    def half(a, ra, b, rb):
+        out = np.zeros((len(a), 16), np.uint32)
+        out[:, 0:6], out[:, 6:12], out[:, 12], out[:, 13] = a, b, ra, rb
+        return out
+
+    binary = half(box6[lc], ref[lc], box6[rc], ref[rc])
+    wide = np.zeros((n - 1, 32), np.uint32)
+    for side, child in ((0, rc), (1, lc)):
+        leaf = child >= n - 1
+        inner = np.where(leaf, 0, child)
+        first, second = nodes[inner, 1], nodes[inner, 0]                    # the child's right child, then its left child
+        a = np.where(leaf[:, None], box6[child], box6[first])
+        ra = np.where(leaf, ref[child], ref[first])
+        b = np.where(leaf[:, None], 0, box6[second])
+        rb = np.where(leaf, NONE, ref[second])
+        wide[:, 16 * side:16 * side + 16] = half(a, ra.astype(np.uint32), b.astype(np.uint32), rb.astype(np.uint32))
+    root = np.zeros(10, np.uint32)
+    root[0:6] = box6[0]
+    root[6] = (LEAF | (nodes[0, 0] if top_level else 0)) if n == 1 else 0
+    root[7] = n
+    return binary, wide, root
+
+
+@pytest.mark.parametrize("n,kind,limit,top_level", [(1, "soup", 64, 0), (2, "soup", 64, 1), (3, "soup", 64, 0), (513, "soup", 64, 0), (5000, "soup", 64, 1),
+                                                    (100000, "soup", 64, 0), (100000, "soup", 0, 0), (70000, "heightfield", 3, 1), (1_200_000, "heightfield", 64, 0)])
+def test_traversal_records_written_by_the_build(cpt, n, kind, limit, top_level):
+    """cpt_builder_build_records: the binary and the two-level records that the hierarchy passes write themselves (from
+    LDS for nodes finished inside a workgroup, from memory for the others, also when the hand-over list is cut short)
+    equal a numpy packing of the tree's reference-format arrays, bit for bit; so does the root record."""
+    mesh = random_soup(n, seed=91 + n) if kind == "soup" else heightfield(int((n / 2) ** 0.5), int((n / 2) ** 0.5), 5)
+    boxes, merged = boxes_of_triangles(mesh["positions"], mesh["indices"])
+    n = len(boxes)
+    d_leaf = cpt.DeviceArray.from_host(boxes)
+    d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
+    d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)
+    slots = max(n - 1, 1)
+    d_binary = cpt.DeviceArray.from_host(np.full((slots, 16), 0xDEADBEEF, np.uint32))
+    d_wide = cpt.DeviceArray.from_host(np.full((slots, 32), 0xDEADBEEF, np.uint32))
+    d_root = cpt.DeviceArray.from_host(np.full(10, 0xDEADBEEF, np.uint32))
+    b = cpt.lib.cpt_builder_create()
+    cpt.check(cpt.lib.cpt_builder_set_carrier_limit(b, limit))
+    for _ in range(2):                                                     # the second build reuses the scratch
+        cpt.check(cpt.lib.cpt_builder_build_records(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, top_level, d_binary.ptr, d_wide.ptr, d_root.ptr))
+    cpt.check(cpt.lib.cpt_synchronize())
+    cpt.lib.cpt_builder_destroy(b)
+    nodes, gboxes = d_nodes.to_host(), d_boxes.to_host()
+    o_nodes, o_boxes, _, _ = oracle_build(boxes, merged)
+    assert np.array_equal(nodes, o_nodes) and np.array_equal(gboxes.view(np.uint32), o_boxes.view(np.uint32))
+    binary, wide, root = records_from_arrays(nodes, gboxes, n, top_level)
+    g_root = d_root.to_host()
+    assert np.array_equal(g_root[:8], root[:8]), (g_root, root)             # flags 0: every coordinate is moderate
+    if n > 1:
+        g_binary, g_wide = d_binary.to_host(), d_wide.to_host()
+        assert np.array_equal(g_binary[:, :14], binary[:, :14]), int((g_binary[:, :14] != binary[:, :14]).any(axis=1).sum())
+        for h in (0, 16):
+            assert np.array_equal(g_wide[:, h:h + 14], wide[:, h:h + 14]), int((g_wide[:, h:h + 14] != wide[:, h:h + 14]).any(axis=1).sum())
