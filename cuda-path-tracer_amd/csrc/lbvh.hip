@@ -1051,7 +1051,7 @@ size_t BuildWorkspace::bytes_for(uint32_t n) {
          + up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock))   // carriers between the two hierarchy passes
          + up(4 * (size_t)cdiv(n, kUpBlock))   // their counts
          + up(4 * (size_t)n)                   // one exchange word per split
-         + up(8 * ((size_t)cdiv(n, 64) + 1))   // one bit per internal node: its records were written by the first hierarchy pass
+         + up(8 * (size_t)cdiv(n, kUpBlock) * (kUpBlock / 64))   // one bit per internal node (one word per wave of the first hierarchy pass): its records were written by that pass
          + up(4 * ((size_t)kPasses * kBins + 64 + (size_t)kPasses * tiles * kBins));   // digit histograms, tile tickets, look-back words
 }
 
@@ -1088,7 +1088,7 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     Carrier *carriers = reinterpret_cast<Carrier *>(p); p += up(sizeof(Carrier) * kCarriersPerGroup * cdiv(n, kUpBlock));
     uint32_t *carrier_counts = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)cdiv(n, kUpBlock));
     uint32_t *slots = reinterpret_cast<uint32_t *>(p); p += up(4 * (size_t)n);
-    unsigned long long *local_mask = reinterpret_cast<unsigned long long *>(p); p += up(8 * ((size_t)cdiv(n, 64) + 1));
+    unsigned long long *local_mask = reinterpret_cast<unsigned long long *>(p); p += up(8 * (size_t)cdiv(n, kUpBlock) * (kUpBlock / 64));
     uint32_t *digit_hist = reinterpret_cast<uint32_t *>(p);            // kPasses x kBins, then first positions
     uint32_t *tickets = digit_hist + kPasses * kBins;                  // one per pass
     uint32_t *tile_status = tickets + 64;                              // kPasses x tiles x kBins
