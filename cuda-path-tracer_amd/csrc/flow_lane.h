@@ -218,6 +218,7 @@ struct Flow {
             const unsigned long long stat_t2 = clock64();
             const int kind = (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) ? 0 : (ct >= ci ? 1 : 2);
             cnt.stats->time[kind] += stat_t1 - stat_t0; cnt.stats->trips[kind]++; cnt.stats->lanes[kind] += kind == 0 ? cn : kind == 1 ? ct : ci;
+            cnt.stats->lanes[5] += cn + ct + ci;      // lanes with a ray, whatever its kind of step
             cnt.stats->time[3] += stat_t2 - stat_t1; cnt.stats->trips[3] += stat_pops != 0; cnt.stats->lanes[3] += stat_pops;
         }
 #endif

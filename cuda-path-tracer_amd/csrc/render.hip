@@ -181,6 +181,9 @@ constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spille
 #endif
 constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
+#ifdef CPT_STEP_STATS
+__device__ unsigned long long g_step_stats[18];      // development build: step statistics of k_render_flow / k_render_pool (trace.h: StepStats)
+#endif
 template <bool MAPS, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
@@ -189,6 +192,11 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
     uint2 spill_entries[kSpillEntries];
     TraceStackT<kLdsStackEntries, kLeafWeightLargeScene, FAST, WIDE> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
     LaneCounters cnt;
+#ifdef CPT_STEP_STATS
+    StepStats stats;
+    cnt.stats = &stats;
+    const unsigned long long stat_begin = clock64();
+#endif
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -202,11 +210,18 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 
     for (;;) {
         // ---- shade the lanes whose extension ray is done
+#ifdef CPT_STEP_STATS
+        const unsigned long long stat_s0 = clock64();
+        stats.lanes[4] += lanes_in(__ballot(s.l.alive && !t.walking()));
+#endif
         if (s.l.alive && !t.walking())
             flow_shade<MAPS>(sc, p, s, t, cnt, [&](V3, V3 dir, float reach, V3 contribution) {
                 s.shadow_dir = dir; s.shadow_tmax = reach; s.pending = contribution;
                 return true;
             });
+#ifdef CPT_STEP_STATS
+        stats.time[4] += clock64() - stat_s0; stats.trips[4]++;
+#endif
 
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
@@ -278,6 +293,10 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
             if (walking == 0 || (waiting > 0 && waiting * 8 >= (walking + waiting) * kFlowShadeEighths)) break;
         }
     }
+#ifdef CPT_STEP_STATS
+    stats.time[5] = clock64() - stat_begin; stats.trips[5] = 1;
+    if (lane == 0) for (int k = 0; k < 6; k++) { atomicAdd(&g_step_stats[k], stats.time[k]); atomicAdd(&g_step_stats[6 + k], stats.trips[k]); atomicAdd(&g_step_stats[12 + k], stats.lanes[k]); }
+#endif
     flush_counters(sc, cnt, paths, s_cnt);
 }
 
@@ -295,9 +314,6 @@ template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5
 #endif
 constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every eighth trip
 
-#ifdef CPT_STEP_STATS
-__device__ unsigned long long g_step_stats[18];
-#endif
 template <bool MAPS, bool DENSE, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
     __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];

@@ -24,7 +24,8 @@ constexpr int kTraceBlock = 256;
 
 #ifdef CPT_STEP_STATS
 // Development build only (make FLAGS+=-DCPT_STEP_STATS): per wave, shader-clock time, trips and participating lanes of
-// every kind of step of the pooled megakernel (0 node, 1 triangle, 2 instance, 3 stack pops, 4 shading, 5 whole kernel).
+// every kind of step of the two persistent megakernels that use Flow::step (0 node, 1 triangle, 2 instance, 3 stack
+// pops, 4 shading, 5 whole kernel; lanes[5]: lanes that had a ray in a traversal trip).
 struct StepStats { unsigned long long time[6] = {0, 0, 0, 0, 0, 0}, trips[6] = {0, 0, 0, 0, 0, 0}, lanes[6] = {0, 0, 0, 0, 0, 0}; };
 struct LaneCounters { uint32_t rays = 0, nodes = 0, tris = 0, shades = 0; StepStats *stats = nullptr; };
 #else
