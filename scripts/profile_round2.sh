@@ -1,7 +1,7 @@
 #!/bin/bash
 # One measurement set on the GPU box: the bench line, rocprofv3 kernel stats of the same command, counter passes for the
 # bounce-loop kernels (Cornell box and the 10M-triangle scene, exact and fast traversal) and the batch query kernel, and
-# the counter-derived values bench.py reads (profiles/r02_counters.json is a copy of <out>/counters.json).
+# (also on the 1M-triangle heightfield and soup), and the counter-derived values bench.py reads (profiles/r02_counters.json is a copy of <out>/counters.json).
 # usage: scripts/profile_round2.sh <tag> [skip-bench]      (results under gpurun_out/<tag>/)
 set -e -o pipefail
 tag=$1
@@ -25,6 +25,16 @@ for trav in 0 1; do
   python3 scripts/pmc_to_json.py "$out/pmc_hf10m_$name" k_render_flow "k_render_flow/heightfield-10m/$name" 32 "$J" "scripts/bench_synth.py heightfield 10000000 3840 2160 32 5 4 $trav 32 (two dispatches of 32 samples)"
   python3 scripts/pmc_to_json.py "$out/pmc_hf10m_$name" k_first_hit "k_first_hit/heightfield-10m/$name" 1 "$J" "same run: 8.3M camera rays per dispatch"
   echo "10M $name counters done"
+done
+# 1M-triangle scenes 1920x1080: camera rays only (the bounce loop runs two samples to keep the passes short)
+for kind in heightfield soup; do
+  for trav in 0 1; do
+    name=$([ $trav = 0 ] && echo exact || echo fast)
+    bash scripts/pmc_passes.sh "$out/pmc_${kind}1m_$name" python3 scripts/bench_synth.py $kind 1000000 1920 1080 2 5 4 $trav 2
+    python3 scripts/pmc_summary.py "$out/pmc_${kind}1m_$name" k_first_hit > "$out/pmc_${kind}1m_${name}_k_first_hit.txt"
+    python3 scripts/pmc_to_json.py "$out/pmc_${kind}1m_$name" k_first_hit "k_first_hit/${kind}-1m/$name" 1 "$J" "scripts/bench_synth.py $kind 1000000 1920 1080 2 5 4 $trav 2: 2.07M camera rays per dispatch"
+  done
+  echo "1M $kind counters done"
 done
 cp "$J" "$root/profiles/r02_counters.json"
 if [ -z "$2" ]; then
