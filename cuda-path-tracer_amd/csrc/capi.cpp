@@ -477,16 +477,20 @@ int cpt_tracer_first_hit(cpt_tracer *t, const float *d_rays, uint64_t num_rays, 
     if (num_rays == 0) return CPT_OK;
     if (!d_rays || !d_instance || !d_primitive) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: null argument");
     if (t->tracer->NumInstances() == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: build_buffers has not produced any geometry");
-    int rc = cpt::launch_first_hit(t->tracer->DeviceScene(), d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, t->tracer->Stream());
-    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "first_hit");
+    return Guard([&] {
+        int rc = cpt::launch_first_hit(t->tracer->DeviceSceneForQueries(), d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, t->tracer->Stream());
+        return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "first_hit");
+    });
 }
 int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint8_t *d_occluded) {
     TRACER_OR_FAIL(t);
     if (num_rays == 0) return CPT_OK;
     if (!d_rays || !d_occluded) return Fail(CPT_ERR_INVALID, "cpt_tracer_occlude: null argument");
     if (t->tracer->NumInstances() == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_occlude: build_buffers has not produced any geometry");
-    int rc = cpt::launch_occlude(t->tracer->DeviceScene(), d_rays, num_rays, d_occluded, t->tracer->Stream());
-    return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "occlude");
+    return Guard([&] {
+        int rc = cpt::launch_occlude(t->tracer->DeviceSceneForQueries(), d_rays, num_rays, d_occluded, t->tracer->Stream());
+        return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "occlude");
+    });
 }
 int cpt_tracer_camera_rays(cpt_tracer *t, uint32_t width, uint32_t height, uint32_t spp, float *d_rays) {
     TRACER_OR_FAIL(t);

@@ -128,7 +128,7 @@ void PathTracer::BuildAccel() {
             mb->nodes.Allocate(sizeof(cpt::AccelNode) * num_nodes);
             mb->bboxes.Allocate(sizeof(cpt::Bbox) * num_nodes);
             mb->keys.Allocate(sizeof(uint64_t) * n);
-            mb->packed_nodes.Allocate(sizeof(cpt::PackedNode) * (n > 1 ? n - 1 : 1));
+            if (!wide) mb->packed_nodes.Allocate(sizeof(cpt::PackedNode) * (n > 1 ? n - 1 : 1));
             mb->tris.Allocate(sizeof(cpt::TriRecord) * n);
             leaf_scratch_.Allocate(sizeof(cpt::Bbox) * (size_t)n);
 
@@ -149,7 +149,7 @@ void PathTracer::BuildAccel() {
             mb->root.Allocate(sizeof(cpt::AccelRoot));
             if (wide) mb->wide_nodes.Allocate(sizeof(cpt::PackedNode) * 2 * (n > 1 ? n - 1 : 1));
             cpt::RecordOutputs records;
-            records.binary = mb->packed_nodes.TypedGpuData<cpt::PackedNode>();
+            records.binary = wide ? nullptr : mb->packed_nodes.TypedGpuData<cpt::PackedNode>();      // with two-level records the binary ones wait for a caller that walks them
             records.wide = wide ? mb->wide_nodes.TypedGpuData<cpt::PackedNode>() : nullptr;
             records.root = mb->root.TypedGpuData<cpt::AccelRoot>();
             rc_check(cpt::lbvh_build(mb->nodes.TypedGpuData<cpt::AccelNode>(), mb->bboxes.TypedGpuData<cpt::Bbox>(), merged, n, stream_, &workspace_,
@@ -182,7 +182,7 @@ void PathTracer::BuildAccel() {
         MeshBuffers &mb = *meshes_[i];
         cpt::MeshDev &d = mesh_table[i];
         memset(&d, 0, sizeof(d));
-        d.nodes = mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
+        d.nodes = wide ? nullptr : mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
         d.tris = mb.tris.TypedGpuData<cpt::TriRecord>();
         d.indices = mb.indices.TypedGpuData<uint32_t>();
         d.positions = mb.positions.TypedGpuData<V3>();
@@ -230,11 +230,11 @@ void PathTracer::BuildAccel() {
     top_bboxes_.Allocate(sizeof(cpt::Bbox) * num_nodes, accel_bboxes.data(), stream_);
     top_nodes_.Allocate(sizeof(cpt::AccelNode) * num_nodes);
     top_keys_.Allocate(sizeof(uint64_t) * num_instances);
-    top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
+    if (!wide) top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
     top_root_.Allocate(sizeof(cpt::AccelRoot));
     if (wide) top_wide_.Allocate(sizeof(cpt::PackedNode) * 2 * (num_instances > 1 ? num_instances - 1 : 1));
     cpt::RecordOutputs top_records;
-    top_records.binary = top_packed_.TypedGpuData<cpt::PackedNode>();
+    top_records.binary = wide ? nullptr : top_packed_.TypedGpuData<cpt::PackedNode>();
     top_records.wide = wide ? top_wide_.TypedGpuData<cpt::PackedNode>() : nullptr;
     top_records.root = top_root_.TypedGpuData<cpt::AccelRoot>();
     top_records.top_level = 1;
@@ -242,9 +242,32 @@ void PathTracer::BuildAccel() {
                              nullptr, top_keys_.TypedGpuData<uint64_t>(), nullptr, nullptr, &top_records), "top-level build");
     scene_dev_.top_wide = wide ? top_wide_.TypedGpuData<cpt::PackedNode>() : nullptr;
     scene_dev_.wide_nodes = wide ? 1 : 0;
-    scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
+    scene_dev_.top_nodes = wide ? nullptr : top_packed_.TypedGpuData<cpt::PackedNode>();
+    binary_records_ = !wide;
     scene_dev_.top_root = top_root_.TypedGpuData<cpt::AccelRoot>();
     scene_dev_.meshes = mesh_table_.TypedGpuData<cpt::MeshDev>();
+}
+
+// The binary node records, for the ordered batch queries: scenes built with two-level records get them the first
+// time such a query asks (0.64 GB of stores per 10M triangles that most renders never need).
+void PathTracer::EnsureBinaryRecords() {
+    if (binary_records_ || !built_ || instance_mesh_.empty()) return;
+    for (size_t i = 0; i < meshes_.size(); i++) {
+        MeshBuffers &mb = *meshes_[i];
+        const uint32_t n = mb.num_triangles;
+        mb.packed_nodes.Allocate(sizeof(cpt::PackedNode) * (n > 1 ? n - 1 : 1));
+        rc_check(cpt::lbvh_pack_binary(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), n, false, stream_),
+                 "binary records");
+        const cpt::PackedNode *records = mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
+        CPT_HIP(hipMemcpyAsync(&mesh_table_.TypedGpuData<cpt::MeshDev>()[i].nodes, &records, sizeof(records), hipMemcpyHostToDevice, stream_));
+    }
+    const uint32_t num_instances = (uint32_t)instance_mesh_.size();
+    top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
+    rc_check(cpt::lbvh_pack_binary(top_packed_.TypedGpuData<cpt::PackedNode>(), top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), num_instances, true, stream_),
+             "binary records, top level");
+    scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
+    CPT_HIP(hipStreamSynchronize(stream_));      // the table entries were copied from locals
+    binary_records_ = true;
 }
 
 // src/pathtracer/pathtracer.cpp:168-221

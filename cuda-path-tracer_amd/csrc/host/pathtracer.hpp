@@ -62,6 +62,9 @@ public:
     uint32_t NumInstances() const { return (uint32_t)instance_mesh_.size(); }
     hipStream_t Stream() const { return stream_; }
     const cpt::SceneDev &DeviceScene() const { return scene_dev_; }
+    // the same for a batch query (first hit, any hit): the ordered traversal of those walks the binary node records,
+    // which a scene built with two-level records gets when the first such query arrives
+    const cpt::SceneDev &DeviceSceneForQueries() { if (scene_dev_.fast_traversal) EnsureBinaryRecords(); return scene_dev_; }
     // Renders sample indices [spp_begin, spp_begin + count) (1-based) into `output` (device,
     // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
     void RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height);
@@ -153,6 +156,8 @@ private:
     cpt::HipBuffer leaf_scratch_;
     cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_, top_wide_;
     int node_records_ = 1;
+    bool binary_records_ = false;              // the binary node records exist (always when node_records_ is 0)
+    void EnsureBinaryRecords();
     cpt::HipBuffer mesh_table_, instance_table_, material_table_, light_table_, counters_;
     cpt::HipBuffer texel_pool_, texture_table_, srgb_table_;
     uint32_t num_lights_ = 0;

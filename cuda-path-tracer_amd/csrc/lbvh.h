@@ -23,8 +23,8 @@ struct BuildWorkspace {
 };
 
 // Traversal records a build may write next to the reference-format arrays (all device pointers): the 64-byte binary
-// records (n - 1, required), the 128-byte two-level records (two PackedNode per internal node; null: not wanted) and
-// the root record.  top_level: leaves are instances (references carry the primitive id) instead of triangles
+// records (n - 1) and the 128-byte two-level records (two PackedNode per internal node), either of which may be null
+// (not wanted), and the root record.  top_level: leaves are instances (references carry the primitive id) instead of triangles
 // (references carry the sorted-leaf position).
 struct RecordOutputs {
     PackedNode *binary = nullptr;
@@ -58,6 +58,9 @@ int lbvh_build_static(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32
 
 // Leaf boxes of a triangle mesh (w = 1), the device counterpart of src/scene/mesh.cpp:88-98.
 int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);
+
+// The binary records of a finished build from its reference-format arrays, for callers that did not ask the build for them.
+int lbvh_pack_binary(PackedNode *out_binary, const AccelNode *nodes, const Bbox *bboxes, uint32_t num_primitives, bool top_level, hipStream_t stream);
 
 // 48-byte triangle records in sorted-leaf order from a finished bottom-level build.
 int lbvh_pack_triangles(TriRecord *out_tris, const AccelNode *nodes, const uint32_t *indices, const V3 *positions, uint32_t num_triangles, hipStream_t stream);

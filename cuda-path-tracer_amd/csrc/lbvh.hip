@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
             float lbox[6], rbox[6];
             const uint32_t lref = slot_of(own.z, lbox), rref = slot_of(own.w, rbox);
             if (!six_in_fast_range(lbox) || !six_in_fast_range(rbox)) atomicOr(&rec.root->flags, 1u);
-            store_half(reinterpret_cast<float4 *>(rec.binary + (b0 + t)), lbox, lref, rbox, rref);
+            if (rec.binary) store_half(reinterpret_cast<float4 *>(rec.binary + (b0 + t)), lbox, lref, rbox, rref);
             if (rec.wide) {
                 float4 *o = reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)(b0 + t));
                 auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) {
@@ -975,9 +975,9 @@ __device__ inline void pack_from_memory(uint32_t i, const RecordOutputs &rec, co
     float lbox[6], rbox[6];
     box6(bboxes[nd.lc_or_id], lbox);
     box6(bboxes[nd.rc], rbox);
-    if (!six_in_fast_range(lbox) || !six_in_fast_range(rbox)) atomicOr(&rec.root->flags, 1u);
+    if (rec.root && (!six_in_fast_range(lbox) || !six_in_fast_range(rbox))) atomicOr(&rec.root->flags, 1u);
     const uint32_t lref = child_ref(nd.lc_or_id, nodes, n, rec.top_level), rref = child_ref(nd.rc, nodes, n, rec.top_level);
-    store_half(reinterpret_cast<float4 *>(rec.binary + i), lbox, lref, rbox, rref);
+    if (rec.binary) store_half(reinterpret_cast<float4 *>(rec.binary + i), lbox, lref, rbox, rref);
     if (!rec.wide) return;
     const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) {
@@ -993,12 +993,12 @@ __device__ inline void pack_from_memory(uint32_t i, const RecordOutputs &rec, co
     half(nd.lc_or_id, lbox, lref, o + 4);
 }
 
-// The root record of a BVH, and the records of the internal nodes the hierarchy pass did not serve (local_mask null:
-// of all of them).  root->flags was zeroed before the build; lanes only ever OR bits into it.
+// The root record of a BVH (when rec.root is given), and the records of the internal nodes the hierarchy pass did not
+// serve (local_mask null: of all of them).  root->flags was zeroed before the build; lanes only ever OR bits into it.
 __global__ void __launch_bounds__(kBlock) k_pack_rest(RecordOutputs rec, const AccelNode *__restrict__ nodes, const Bbox *__restrict__ bboxes, uint32_t n,
                                                        const unsigned long long *__restrict__ local_mask) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) {
+    if (i == 0 && rec.root) {
         const Bbox b = bboxes[0];
         AccelRoot *root = rec.root;
         root->bmin[0] = b.pmin.x; root->bmin[1] = b.pmin.y; root->bmin[2] = b.pmin.z;
@@ -1074,7 +1074,7 @@ void BuildWorkspace::release() {
 int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, hipStream_t stream, BuildWorkspace *ws_in,
                const Bbox *leaf_src_in, uint64_t *keys_out, uint32_t *parents_out, float *stage_ms, const RecordOutputs *records) {
     if (n == 0) return 0;
-    if (records && (!records->binary || !records->root)) return (int)hipErrorInvalidValue;
+    if (records && (!records->root || (!records->binary && !records->wide))) return (int)hipErrorInvalidValue;
     BuildWorkspace local;
     BuildWorkspace *ws = ws_in ? ws_in : &local;
     int rc = ws->reserve(n);
@@ -1243,6 +1243,15 @@ int lbvh_build_static(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32
 int lbvh_triangle_boxes(Bbox *leaf, const uint32_t *indices, const V3 *positions, uint32_t n, hipStream_t stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_tri_boxes, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, leaf, indices, positions, n);
+    return (int)hipGetLastError();
+}
+
+int lbvh_pack_binary(PackedNode *out_binary, const AccelNode *nodes, const Bbox *bboxes, uint32_t n, bool top_level, hipStream_t stream) {
+    if (n < 2) return 0;
+    RecordOutputs rec;
+    rec.binary = out_binary;
+    rec.top_level = top_level ? 1 : 0;
+    hipLaunchKernelGGL(k_pack_rest, dim3(cdiv(n - 1, kBlock)), dim3(kBlock), 0, stream, rec, nodes, bboxes, n, (const unsigned long long *)nullptr);
     return (int)hipGetLastError();
 }
 

@@ -168,14 +168,16 @@ int cpt_tracer_set_integrator(cpt_tracer *t, int mode);
  * reported (the nearest; at exactly equal distance the one later in instance and sorted-leaf order).  Applies to
  * cpt_tracer_first_hit / cpt_tracer_occlude and to integrators 3, 4 and 5; integrators 0, 1 and 2 always run exact. */
 int cpt_tracer_set_traversal(cpt_tracer *t, int mode);
-/* Node records of the exact traversal (no counterpart in the reference, which walks one AccelNode and two Bbox per step,
- * accel.cuh:68-90): next to the 64-byte binary records the build lays down two-level records, 128 bytes per internal
- * node holding the boxes and references of its (up to four) grandchildren in the order accel.cuh:84-91 reaches them.
- * A ray then fetches half as many dependent records in half as many traversal steps; because a child's box lies inside
- * its parent's and every operation of BboxIntersect is monotonic in the box coordinates, testing the grandchildren
- * directly walks exactly the leaves the reference walks, in its order: results stay bit-exact.  Every kernel walks them
- * in exact traversal; the ordered traversal walks the binary records.  mode: 1 = built (default), 0 = binary records
- * only (the exact traversal then walks those); takes effect at the next cpt_tracer_build_buffers. */
+/* Node records of the traversal (no counterpart in the reference, which walks one AccelNode and two Bbox per step,
+ * accel.cuh:68-90).  Binary records: 64 bytes per internal node, both children's boxes and references.  Two-level
+ * records: 128 bytes per internal node, the boxes and references of its (up to four) grandchildren in the order
+ * accel.cuh:84-91 reaches them.  On those a ray fetches half as many dependent records in half as many traversal steps;
+ * because a child's box lies inside its parent's and every operation of BboxIntersect is monotonic in the box
+ * coordinates, testing the grandchildren directly walks exactly the leaves the reference walks, in its order: results
+ * stay bit-exact.  mode 1 (default): the build writes two-level records, every kernel walks them in exact traversal
+ * and the bounce loops in ordered traversal too; the ordered batch queries walk binary records, which are then made
+ * when the first such query arrives.  mode 0: binary records only, walked by everything.  Takes effect at the next
+ * cpt_tracer_build_buffers. */
 int cpt_tracer_set_node_records(cpt_tracer *t, int mode);
 /* Wavefront integrator only: after `bounces` queue bounces the paths still alive are finished by
  * one persistent launch that keeps each path in registers (the long, thin tail of Russian-roulette
