@@ -44,7 +44,7 @@ struct AccelRoot {
 };
 
 struct MeshDev {
-    const PackedNode *nodes;
+    const PackedNode *nodes;    // binary records; null until something that walks them asks (scenes built with two-level records)
     const TriRecord *tris;
     const uint32_t *indices;
     const V3 *positions;
@@ -53,7 +53,7 @@ struct MeshDev {
     AccelRoot root;
     uint32_t num_triangles;
     uint32_t pad;
-    const PackedNode *wide;     // two records per internal node (see k_pack_wide), or null
+    const PackedNode *wide;     // two-level records: two PackedNode-shaped halves per internal node (lbvh.hip: pack_from_memory), or null
 };
 
 struct InstanceDev {

@@ -88,8 +88,8 @@ public:
     // (morton, sort, gather, karras, refit), valid after SetProfileBuild(true)
     void SetProfileBuild(bool on) { profile_build_ = on; }
     const float *BuildStageMs() const { return build_stage_ms_; }
-    // the same mesh's triangle-box kernel before the build and record-packing kernels after it: what has to run besides
-    // the build before a ray can be traced
+    // the same mesh's triangle-box kernel before the build and triangle-record kernel after it (the node records come
+    // out of the build itself): what has to run besides the build before a ray can be traced
     float LeafBoxesMs() const { return leaf_boxes_ms_; }
     float PackMs() const { return pack_ms_; }
 

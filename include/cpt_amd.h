@@ -257,8 +257,9 @@ int cpt_tracer_stack_overflows(cpt_tracer *t, uint64_t *count);
 int cpt_tracer_reset_counters(cpt_tracer *t);
 int cpt_tracer_build_stage_ms(cpt_tracer *t, float out5[5]);
 /* With cpt_tracer_set_profile_build: device milliseconds of the kernels that frame the largest mesh's build before a ray can
- * be traced: out2[0] the per-triangle leaf boxes (src/scene/mesh.cpp:88-98 computes them on the host), out2[1] packing nodes
- * and triangles into traversal records.  Build + these two = time to a traversable BVH. */
+ * be traced: out2[0] the per-triangle leaf boxes (src/scene/mesh.cpp:88-98 computes them on the host), out2[1] the triangle
+ * records (the node records are written by the build's own hierarchy kernels and are part of its stage times).  Build +
+ * these two = time to a traversable BVH. */
 int cpt_tracer_build_extra_ms(cpt_tracer *t, float out2[2]);
 
 /* ---- several GPUs of one node -----------------------------------------------------------------
