@@ -307,3 +307,13 @@ def test_two_level_records_walk_the_same_leaves(cpt, scene):
     short[:, 7] = 0.45
     assert np.array_equal(binary.occlude(short), wide.occlude(short))
     assert np.array_equal(wide.occlude(short[:100000]), osc.occlude(short[:100000]))
+    # the ordered traversal of the batch queries walks binary records, which the scene built with two-level records
+    # makes when the first such query arrives; exact results are untouched by that
+    wide.set_traversal(1)
+    f = wide.first_hit(rays[:50000])
+    wide.set_traversal(0)
+    again = wide.first_hit(rays[:50000])
+    for x, y in zip(again, w):
+        assert np.array_equal(x.view(np.uint32), y[:50000].view(np.uint32))
+    assert (f[2] <= again[2]).all()                           # never a farther hit
+    assert cpt.lib.cpt_tracer_set_node_records(wide.h, 2) < 0 and cpt.lib.cpt_tracer_set_node_records(wide.h, -1) < 0
