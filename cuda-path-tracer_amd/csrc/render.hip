@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 // did on a scene that sits in the vector L1 (cornell-box-glass: 1.66 against 1.42 ms per sample);
 // with long rays through a large BVH it wins (heightfield 10M: 248 -> 395 Mpaths/s, soup 1M 73 -> 104).
 // Four waves per SIMD and 16 LDS stack entries for every scene: five waves measured the same, six spill.
-constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spilled) and 2 waves measured: heightfield 10M 424 and 302 against 468 Mpaths/s: residency beats spills here
+constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spilled) and 2 waves measured: heightfield 10M 424 and 302 against 468 Mpaths/s on binary records, 3 waves 525 against 545 on two-level ones (soup 1M 197 against 217): residency beats spills here
 #ifndef FLOW_NUM
 #define FLOW_NUM 3
 #endif
