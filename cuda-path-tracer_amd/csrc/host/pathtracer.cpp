@@ -252,21 +252,22 @@ void PathTracer::BuildAccel() {
 // time such a query asks (0.64 GB of stores per 10M triangles that most renders never need).
 void PathTracer::EnsureBinaryRecords() {
     if (binary_records_ || !built_ || instance_mesh_.empty()) return;
+    std::vector<const cpt::PackedNode *> table_entries(meshes_.size());      // lives until the copies below have been waited for
     for (size_t i = 0; i < meshes_.size(); i++) {
         MeshBuffers &mb = *meshes_[i];
         const uint32_t n = mb.num_triangles;
         mb.packed_nodes.Allocate(sizeof(cpt::PackedNode) * (n > 1 ? n - 1 : 1));
         rc_check(cpt::lbvh_pack_binary(mb.packed_nodes.TypedGpuData<cpt::PackedNode>(), mb.nodes.TypedGpuData<cpt::AccelNode>(), mb.bboxes.TypedGpuData<cpt::Bbox>(), n, false, stream_),
                  "binary records");
-        const cpt::PackedNode *records = mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
-        CPT_HIP(hipMemcpyAsync(&mesh_table_.TypedGpuData<cpt::MeshDev>()[i].nodes, &records, sizeof(records), hipMemcpyHostToDevice, stream_));
+        table_entries[i] = mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
+        CPT_HIP(hipMemcpyAsync(&mesh_table_.TypedGpuData<cpt::MeshDev>()[i].nodes, &table_entries[i], sizeof(table_entries[i]), hipMemcpyHostToDevice, stream_));
     }
     const uint32_t num_instances = (uint32_t)instance_mesh_.size();
     top_packed_.Allocate(sizeof(cpt::PackedNode) * (num_instances > 1 ? num_instances - 1 : 1));
     rc_check(cpt::lbvh_pack_binary(top_packed_.TypedGpuData<cpt::PackedNode>(), top_nodes_.TypedGpuData<cpt::AccelNode>(), top_bboxes_.TypedGpuData<cpt::Bbox>(), num_instances, true, stream_),
              "binary records, top level");
     scene_dev_.top_nodes = top_packed_.TypedGpuData<cpt::PackedNode>();
-    CPT_HIP(hipStreamSynchronize(stream_));      // the table entries were copied from locals
+    CPT_HIP(hipStreamSynchronize(stream_));
     binary_records_ = true;
 }
 
