@@ -187,7 +187,8 @@ int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void 
 
 int cpt_builder_build_records(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8], uint32_t num_primitives,
                               int top_level, void *d_binary_records, void *d_two_level_records, void *d_root_record) {
-    if (!b || !d_nodes || !d_bboxes || !merged_bbox || !d_binary_records || !d_root_record) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: null argument");
+    if (!b || !d_nodes || !d_bboxes || !merged_bbox || !d_root_record) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: null argument");
+    if (!d_binary_records && !d_two_level_records) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: neither binary nor two-level records asked for");
     if (num_primitives == 0) return CPT_OK;
     if (num_primitives > 0x7fffffffu) return Fail(CPT_ERR_INVALID, "cpt_builder_build_records: more than 2^31-1 primitives");
     cpt::RecordOutputs records;

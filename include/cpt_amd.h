@@ -90,11 +90,12 @@ int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void 
 
 /* cpt_builder_build and, in the same kernels, the traversal records of the tree (no counterpart in the reference, whose
  * traversal reads AccelNode and Bbox, accel.cuh:68-90): num_primitives - 1 binary records of 64 bytes (left child's box
- * min.xyz max.xyz, right child's, left reference, right reference, 8 spare bytes), optionally (may be null) as many
- * two-level records of 128 bytes (two halves in that layout: the right child's children, right one first, then the left
- * child's; a child that is a leaf fills the first slot of its half and leaves 0xffffffff as the second reference), and a
- * root record of 40 bytes (box min.xyz max.xyz, reference, primitive count, flags, spare).  A reference with bit 31
- * set is a leaf: its sorted position, or with top_level != 0 the primitive id.  Only enqueues work. */
+ * min.xyz max.xyz, right child's, left reference, right reference, 8 spare bytes) and / or as many two-level records of
+ * 128 bytes (two halves in that layout: the right child's children, right one first, then the left child's; a child
+ * that is a leaf fills the first slot of its half and leaves 0xffffffff as the second reference) -- either pointer may
+ * be null, not both -- and a root record of 40 bytes (box min.xyz max.xyz, reference, primitive count, flags, spare).
+ * A reference with bit 31 set is a leaf: its sorted position, or with top_level != 0 the primitive id.  Only enqueues
+ * work. */
 int cpt_builder_build_records(cpt_builder *b, void *d_nodes, void *d_bboxes, const void *d_leaf_boxes, const float merged_bbox[8], uint32_t num_primitives,
                               int top_level, void *d_binary_records, void *d_two_level_records, void *d_root_record);
 

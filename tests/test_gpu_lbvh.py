@@ -262,7 +262,15 @@ def test_traversal_records_written_by_the_build(cpt, n, kind, limit, top_level):
     binary, wide, root = records_from_arrays(nodes, gboxes, n, top_level)
     g_root = d_root.to_host()
     assert np.array_equal(g_root[:8], root[:8]), (g_root, root)             # flags 0: every coordinate is moderate
+    # either kind of record alone
+    b = cpt.lib.cpt_builder_create()
+    d_wide_only = cpt.DeviceArray.from_host(np.full((slots, 32), 0xDEADBEEF, np.uint32))
+    cpt.check(cpt.lib.cpt_builder_build_records(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, top_level, None, d_wide_only.ptr, d_root.ptr))
+    assert cpt.lib.cpt_builder_build_records(b, d_nodes.ptr, d_boxes.ptr, d_leaf.ptr, merged, n, top_level, None, None, d_root.ptr) < 0
+    cpt.check(cpt.lib.cpt_synchronize())
+    cpt.lib.cpt_builder_destroy(b)
     if n > 1:
+        assert np.array_equal(d_wide_only.to_host()[:, :14], wide[:, :14]) and np.array_equal(d_wide_only.to_host()[:, 16:30], wide[:, 16:30])
         g_binary, g_wide = d_binary.to_host(), d_wide.to_host()
         assert np.array_equal(g_binary[:, :14], binary[:, :14]), int((g_binary[:, :14] != binary[:, :14]).any(axis=1).sum())
         for h in (0, 16):
