@@ -44,6 +44,7 @@ _sig("cpt_memcpy_h2d", C.c_int, [_vp, _vp, C.c_size_t])
 _sig("cpt_memcpy_d2h", C.c_int, [_vp, _vp, C.c_size_t])
 _sig("cpt_memset", C.c_int, [_vp, C.c_int, C.c_size_t])
 _sig("cpt_synchronize", C.c_int, [])
+_sig("cpt_memory_info", C.c_int, [_vp, _vp])
 _sig("cpt_build_accel", C.c_int, [_vp, _vp, _f32, C.c_uint32])
 _sig("cpt_build_accel_ex", C.c_int, [_vp, _vp, _f32, C.c_uint32, _vp, _vp, _vp])
 _sig("cpt_build_accel_noalloc", C.c_int, [_vp, _vp, _f32, C.c_uint32])
@@ -113,6 +114,7 @@ _sig("cpt_shard_samples", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint
 _sig("cpt_comm_unique_id", C.c_int, [_vp])
 _sig("cpt_comm_create", _vp, [_vp, C.c_int, C.c_int])
 _sig("cpt_comm_destroy", None, [_vp])
+_sig("cpt_comm_census", C.c_int, [_vp, _vp, _vp, _vp])
 _sig("cpt_tracer_reduce_film", C.c_int, [_vp, _vp, C.c_int, C.c_int])
 _sig("cpt_multi_create", _vp, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32])
 _sig("cpt_multi_destroy", None, [_vp])
@@ -130,6 +132,7 @@ _sig("cpt_multi_reset_counters", C.c_int, [_vp])
 _sig("cpt_multi_num_devices", C.c_uint32, [_vp])
 _sig("cpt_selftest_division", C.c_int, [C.c_uint64, C.c_uint32, _vp])
 _sig("cpt_stream_copy_rate", C.c_int, [C.c_uint64, C.c_int, _vp])
+_sig("cpt_valu_issue_rate", C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp])
 _sig("cpt_write_exr", C.c_int, [C.c_char_p, _f32, C.c_uint32, C.c_uint32])
 _sig("cpt_image_load", C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_size_t])
 _sig("cpt_image_save_png", C.c_int, [C.c_char_p, _vp, C.c_uint32, C.c_uint32])
@@ -148,6 +151,13 @@ def check(rc):
 
 def device_count():
     return lib.cpt_device_count()
+
+
+def memory_info():
+    """(free, total) bytes of the current device."""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    check(lib.cpt_memory_info(C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
 
 
 def require_device():
@@ -496,6 +506,12 @@ class Comm:
         if not self.h:
             raise CptError(lib.cpt_last_error().decode("utf-8", "replace"))
         self.rank, self.world = rank, world
+
+    def census(self):
+        """(ranks, rank, device) as RCCL reports them for this communicator."""
+        n, r, d = C.c_int(0), C.c_int(-1), C.c_int(-1)
+        check(lib.cpt_comm_census(self.h, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
 
     def close(self):
         if self.h:

@@ -5,7 +5,9 @@
 
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "host/film.hpp"
 #include "host/loader.hpp"
@@ -27,6 +29,8 @@ int HipFail(hipError_t e, const char *what) { return Fail(CPT_ERR_DEVICE, std::s
 template <typename F> int Guard(F &&fn) {
     try {
         return fn();
+    } catch (const std::invalid_argument &e) {
+        return Fail(CPT_ERR_INVALID, e.what());
     } catch (const std::exception &e) {
         return Fail(CPT_ERR_DEVICE, e.what());
     } catch (...) {
@@ -109,6 +113,11 @@ int cpt_memset(void *d_dst, int value, size_t bytes) {
 int cpt_synchronize(void) {
     hipError_t e = hipDeviceSynchronize();
     return e == hipSuccess ? CPT_OK : HipFail(e, "hipDeviceSynchronize");
+}
+int cpt_memory_info(size_t *free_bytes, size_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return Fail(CPT_ERR_INVALID, "cpt_memory_info: null argument");
+    hipError_t e = hipMemGetInfo(free_bytes, total_bytes);
+    return e == hipSuccess ? CPT_OK : HipFail(e, "hipMemGetInfo");
 }
 
 // ------------------------------------------------------------------ LBVH
@@ -610,6 +619,17 @@ cpt_comm *cpt_comm_create(const uint8_t id[128], int rank, int world) {
 
 void cpt_comm_destroy(cpt_comm *c) { delete c; }
 
+int cpt_comm_census(const cpt_comm *c, int *ranks, int *rank, int *device) {
+    if (!c) return Fail(CPT_ERR_INVALID, "cpt_comm_census: null communicator");
+    return Guard([&] {
+        const cpt::ShardComm::CensusResult seen = c->comm->Census();
+        if (ranks) *ranks = seen.ranks;
+        if (rank) *rank = seen.rank;
+        if (device) *device = seen.device;
+        return CPT_OK;
+    });
+}
+
 int cpt_tracer_reduce_film(cpt_tracer *t, cpt_comm *c, int root, int finish) {
     TRACER_OR_FAIL(t);
     if (!c || root < 0 || root >= c->comm->World()) return Fail(CPT_ERR_INVALID, "cpt_tracer_reduce_film: bad communicator or root");
@@ -736,6 +756,47 @@ int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s) {
         (void)hipEventDestroy(e1);
         if (rc != 0) return HipFail((hipError_t)rc, "stream_copy");
         *gb_per_s = 2.0 * (double)(bytes / 16 * 16) * repeats / ((double)ms * 1e-3) / 1e9;     // bytes read + bytes written
+        return (int)CPT_OK;
+    });
+}
+
+int cpt_valu_issue_rate(int mix, int waves_per_simd, double *ginst_per_s, double *cycles_per_inst, double *shader_mhz) {
+    if (!ginst_per_s || mix < 0 || mix > 1 || waves_per_simd < 1 || waves_per_simd > 8) return Fail(CPT_ERR_INVALID, "cpt_valu_issue_rate: mix 0 or 1, 1 to 8 waves per SIMD");
+    return Guard([&] {
+        int device = 0, cus = 0;
+        CPT_HIP(hipGetDevice(&device));
+        CPT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        const uint32_t iterations = 4096;                      // x 64 instructions per trip
+        const size_t waves = (size_t)cus * waves_per_simd * 4;
+        cpt::HipBuffer sink(sizeof(float)), cycles(sizeof(unsigned long long) * waves);
+        cycles.Zero();
+        hipEvent_t e0, e1;
+        CPT_HIP(hipEventCreate(&e0));
+        CPT_HIP(hipEventCreate(&e1));
+        int rc = cpt::launch_valu_rate(mix, waves_per_simd, cus, iterations, sink.TypedGpuData<float>(), cycles.TypedGpuData<unsigned long long>(), nullptr);   // warm-up: clocks up
+        const int repeats = 5;
+        if (rc == 0) {
+            CPT_HIP(hipEventRecord(e0, nullptr));
+            for (int k = 0; k < repeats && rc == 0; k++)
+                rc = cpt::launch_valu_rate(mix, waves_per_simd, cus, iterations, sink.TypedGpuData<float>(), cycles.TypedGpuData<unsigned long long>(), nullptr);
+            CPT_HIP(hipEventRecord(e1, nullptr));
+            CPT_HIP(hipEventSynchronize(e1));
+        }
+        float ms = 0.0f;
+        if (rc == 0) CPT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc != 0) return HipFail((hipError_t)rc, "valu_rate");
+        std::vector<unsigned long long> host(waves);
+        CPT_HIP(hipMemcpy(host.data(), cycles.GpuData(), sizeof(unsigned long long) * waves, hipMemcpyDeviceToHost));
+        double sum = 0.0;
+        for (unsigned long long c : host) sum += (double)c;
+        const double per_wave = (double)iterations * 64.0;
+        const double seconds = (double)ms * 1e-3 / repeats;
+        *ginst_per_s = per_wave * (double)waves / seconds / 1e9;
+        if (cycles_per_inst) *cycles_per_inst = sum / (double)waves / per_wave;
+        // a launch lasts as long as its waves do (they all start together): shader clock = a wave's cycles / the launch time
+        if (shader_mhz) *shader_mhz = sum / (double)waves / seconds / 1e6;
         return (int)CPT_OK;
     });
 }

@@ -27,6 +27,9 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -54,6 +57,9 @@ const Rccl &rccl() {
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
+        api.CommCuDevice = reinterpret_cast<decltype(api.CommCuDevice)>(sym("ncclCommCuDevice"));
         api.Reduce = reinterpret_cast<decltype(api.Reduce)>(sym("ncclReduce"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
@@ -130,6 +136,15 @@ std::unique_ptr<ShardComm> ShardComm::InitRank(const std::array<char, kCommIdByt
     return c;
 }
 
+// what the communicator itself says about its size, this rank and its device (not what it was asked for)
+ShardComm::CensusResult ShardComm::Census() const {
+    CensusResult r{0, -1, -1};
+    rccl_check(rccl().CommCount(static_cast<ncclComm_t>(comm_), &r.ranks), "ncclCommCount");
+    rccl_check(rccl().CommUserRank(static_cast<ncclComm_t>(comm_), &r.rank), "ncclCommUserRank");
+    rccl_check(rccl().CommCuDevice(static_cast<ncclComm_t>(comm_), &r.device), "ncclCommCuDevice");
+    return r;
+}
+
 void ShardComm::ReduceSum(float *d_buffer, size_t count, int root, hipStream_t stream) {
     if (root < 0 || root >= world_) throw std::invalid_argument("ShardComm::ReduceSum: root outside the world");
     rccl_check(rccl().Reduce(d_buffer, d_buffer, count, ncclFloat, ncclSum, root, static_cast<ncclComm_t>(comm_), stream), "ncclReduce");
@@ -177,6 +192,13 @@ MultiPathTracer::MultiPathTracer(Scene &scene, Film &film, std::vector<int> shar
         shards_.push_back(std::move(s));
     }
     comms_ = cpt::ShardComm::InitAll(distinct);
+    for (size_t r = 0; r < comms_.size(); r++) {
+        const cpt::ShardComm::CensusResult seen = comms_[r]->Census();
+        if (seen.ranks != (int)distinct.size() || seen.rank != (int)r || seen.device != distinct[r])
+            throw std::runtime_error("MultiPathTracer: RCCL reports " + std::to_string(seen.ranks) + " ranks, rank " + std::to_string(seen.rank) + " on device " +
+                                     std::to_string(seen.device) + " where rank " + std::to_string(r) + " of " + std::to_string(distinct.size()) + " on device " +
+                                     std::to_string(distinct[r]) + " was asked for");
+    }
     for (size_t i = 0; i < shards_.size(); i++) {
         Shard &s = shards_[i];
         DeviceScope scope(s.device);
@@ -186,6 +208,9 @@ MultiPathTracer::MultiPathTracer(Scene &scene, Film &film, std::vector<int> shar
             s.own_film = std::make_unique<Film>(film_.Width(), film_.Height());
             s.film = s.own_film.get();
         }
+        // a Film takes its device memory at first use, on whichever device is current then: take it here, on the
+        // shard's own device, the caller's film of shard 0 included
+        (void)s.film->DeviceMap(nullptr);
         s.tracer = std::make_unique<PathTracer>(scene_, *s.film);
         CPT_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
@@ -243,7 +268,8 @@ uint32_t MultiPathTracer::NumLights() const { return shards_.front().tracer->Num
 
 void MultiPathTracer::Render(uint32_t total_spp, uint32_t first, void (*progress)(uint32_t, void *), void *user) {
     if (!built_) throw std::runtime_error("MultiPathTracer::Render before BuildBuffers");
-    if (film_.Width() != shards_.front().film->Width()) throw std::runtime_error("MultiPathTracer: film resized");
+    for (const Shard &s : shards_)
+        if (s.film->Width() != film_.Width() || s.film->Height() != film_.Height()) throw std::runtime_error("MultiPathTracer: film resized");
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t world = (uint32_t)shards_.size();
     std::mutex progress_mutex;

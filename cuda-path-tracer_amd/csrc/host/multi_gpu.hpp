@@ -48,6 +48,9 @@ public:
     int Rank() const { return rank_; }
     int World() const { return world_; }
     int Device() const { return device_; }
+    // ncclCommCount / ncclCommUserRank / ncclCommCuDevice of this communicator: what RCCL made, not what was asked for
+    struct CensusResult { int ranks, rank, device; };
+    CensusResult Census() const;
     // in-place sum of `count` floats over all ranks into `root`'s buffer, ordered on `stream`
     void ReduceSum(float *d_buffer, size_t count, int root, hipStream_t stream);
     // several ranks of one process must be called between these two

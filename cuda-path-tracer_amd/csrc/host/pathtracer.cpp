@@ -41,7 +41,8 @@ void PathTracer::BuildBuffers() {
     scene_.ForEach<const MeshComponent>([&](const MeshComponent &mesh) { triangles += mesh.GetMesh()->IndicesCount() / 3; });
     scene_triangles_ = triangles;
     const bool dense = triangles >= kLargeSceneTriangles;
-    if (dense != wf_dense_) { wf_dense_ = dense; wf_.capacity = 0; }      // the resident workgroup count is looked up again
+    const bool wide = scene_dev_.wide_nodes != 0;
+    if (dense != wf_dense_ || wide != wf_wide_) { wf_dense_ = dense; wf_wide_ = wide; wf_.capacity = 0; }      // the resident workgroup counts are looked up again: they depend on the kernel build
     scene_dev_.large_scene = dense ? 1 : 0;
     CPT_HIP(hipStreamSynchronize(stream_));
     built_ = true;
@@ -69,7 +70,7 @@ bool PathTracer::CameraFromScene(cpt::CameraDev &out) {
 // revision moved gets its parameter block rebuilt, a camera whose values moved is re-derived, and either restarts
 // the accumulation.  As in the reference, the light table is not remade (an edit does not turn an object into a
 // light or back; BuildBuffers does).
-bool PathTracer::RefreshEdits() {
+bool PathTracer::RefreshEdits(bool restart) {
     bool changed = false;
     cpt::CameraDev camera = scene_dev_.camera;
     if (CameraFromScene(camera) && memcmp(&camera, &scene_dev_.camera, sizeof(camera)) != 0) {
@@ -90,7 +91,10 @@ bool PathTracer::RefreshEdits() {
         material_table_.SetData(blocks.data(), sizeof(cpt::BsdfDev) * blocks.size(), stream_);
         changed = true;
     }
-    if (changed) {
+    if (changed && !restart) restart_pending_ = true;      // the tables are current; the film is restarted by the next caller that owns it
+    if ((changed || restart_pending_) && restart) {
+        restart_pending_ = false;
+        changed = true;
         ResetAccumelation();
         film_.Clear(stream_);
         film_alpha_unit_ = true;
@@ -542,7 +546,8 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
     RefreshEdits();
-    if (!output && sum_mode) film_alpha_unit_ = false;        // the film's alpha becomes a sample count
+    // the film's alpha becomes a sample count, also when the caller passes the film's own pointer back in
+    if (sum_mode && (!output || output == film_.DeviceMap(stream_))) film_alpha_unit_ = false;
     cpt::RenderParams p;
     p.output = output ? output : film_.DeviceMap(stream_);
     p.width = output ? width : film_.Width();
@@ -555,11 +560,15 @@ void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode
 }
 
 // kernel::PathTracer::Render(const Params &) (src/kernels/integrator/path.cu:109-115): one sample per pixel with the
-// values of the call, into `output`, finished on return; the tracer's own settings and sample counter are not touched
+// values of the call, into `output`, finished on return; the tracer's own settings, film and sample counter are not
+// touched (edited materials and a moved camera reach the device tables; the restart of the tracer's own accumulation
+// that such an edit asks for is left to the next Update).  A scene without lights renders nothing, as
+// PathTracer::Update returns early for it (src/pathtracer/pathtracer.cpp:27-29): the light table does not exist.
 void PathTracer::RenderOneSample(float *output, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth, int channel) {
     if (!built_ || !has_camera_ || instance_mesh_.empty()) throw std::runtime_error("PathTracer::RenderOneSample before BuildBuffers produced a scene");
     if (!output || width == 0 || height == 0 || spp == 0) throw std::invalid_argument("PathTracer::RenderOneSample: bad argument");
-    RefreshEdits();
+    if (num_lights_ == 0) throw std::invalid_argument("PathTracer::RenderOneSample: the scene has no emissive object");
+    RefreshEdits(false);
     cpt::RenderParams p;
     p.output = output;
     p.width = width;

@@ -95,8 +95,9 @@ public:
 
     // Looks for edits made to the scene's materials (Material::SetChanged) and camera since the device tables were
     // written, re-uploads what moved and restarts the accumulation; Update and UpdateMany call it.  Returns whether
-    // anything had changed.
-    bool RefreshEdits();
+    // anything had changed.  With restart == false the device tables are brought up to date but film and sample counter
+    // are left alone; the restart then happens at the next call that asks for it.
+    bool RefreshEdits(bool restart = true);
 
 private:
     void BuildAccel();
@@ -132,6 +133,7 @@ private:
     int resident_blocks_ = 0;
     cpt::HipBuffer queue_;
     cpt::HipBuffer order_;                 // one word per pixel for launches of several samples (RenderParams::order)
+    bool restart_pending_ = false;         // an edit was uploaded by RefreshEdits(false); the accumulation has not been restarted yet
     bool film_alpha_unit_ = true;          // every alpha of the film is 0 or 1: nothing but running-mean samples and clears has written it
     uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample (later, with 0.824 at 32: 64 -> 0.817, 128 -> 0.814, 256 -> 0.813, 1024 -> 0.811)
     void LaunchSample(const cpt::RenderParams &p);
@@ -141,6 +143,7 @@ private:
     cpt::WavefrontBuffers wf_{};
     int wf_resident_blocks_ = 0, wf_finish_blocks_ = 0;
     bool wf_dense_ = false;          // set by BuildBuffers from the scene's triangle count: which build of the persistent kernels runs
+    bool wf_wide_ = false;           // the wavefront kernels' resident counts were looked up for two-level records
     bool resident_dense_ = false;
     int resident_variant_ = 0;
     int resident_traversal_ = -1;      // bit 0: ordered traversal, bit 1: two-level records

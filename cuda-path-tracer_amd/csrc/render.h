@@ -32,6 +32,7 @@ int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_misma
 
 // Copies bytes / 16 * 16 bytes from src to dst (both 16-byte aligned device memory) with a plain streaming kernel.
 int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t stream);
+int launch_valu_rate(int mix, int waves_per_simd, int compute_units, uint32_t iterations, float *sink, unsigned long long *cycles, hipStream_t stream);
 
 // Films of sharded renders (W*H float4 each): dst += src; sums with the sample count in alpha -> mean with alpha 1.
 int launch_film_add(float *dst, const float *src, uint64_t pixels, hipStream_t stream);

@@ -563,6 +563,46 @@ __global__ void __launch_bounds__(256) k_stream_copy(const RawF4 *__restrict__ s
     if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
+// Vector-instruction issue rate of the device, measured: every wave runs `iterations` trips of 64 independent vector
+// instructions on 16 accumulators (no memory access, no dependence shorter than 16 instructions) and notes the shader
+// clock before and after.  MIX 0: v_fma_f32 only.  MIX 1: the kinds a slab test is made of (subtract, multiply,
+// compare + select, max, min).  The host sizes the grid so that a chosen number of waves shares each SIMD; the quotient
+// instructions / time over the whole device is the ceiling a traversal kernel's instruction count is set against.
+template <int MIX>
+__global__ void __launch_bounds__(256) k_valu_rate(uint32_t iterations, float seed, float *sink, unsigned long long *cycles) {
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = seed + (float)(threadIdx.x + k);
+    const float x = 1.0f + seed * 1e-9f, y = seed * 1e-3f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (uint32_t i = 0; i < iterations; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (MIX == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k += 8) {
+                    asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[k]) : "v"(x));
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k + 1]) : "v"(x));
+                    asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %1, %2, vcc" : "+v"(a[k + 2]) : "v"(a[k + 3]), "v"(y) : "vcc");
+                    asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[k + 4]) : "v"(y));
+                    asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[k + 5]) : "v"(x));
+                    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k + 6]) : "v"(y));
+                    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k + 7]) : "v"(x));
+                }
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) total += a[k];
+    if (total == 123.456f) sink[0] = total;            // keeps the accumulators alive; never true for the seeds used
+    if ((threadIdx.x & 63u) == 0u) cycles[(blockIdx.x * 256u + threadIdx.x) >> 6] = t1 - t0;
+}
+
 // d_dst += d_src, one float4 (pixel) per lane and trip
 __global__ void __launch_bounds__(256) k_film_add(RawF4 *__restrict__ dst, const RawF4 *__restrict__ src, unsigned long long pixels) {
     const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
@@ -601,6 +641,19 @@ int launch_stream_copy(const void *src, void *dst, uint64_t bytes, hipStream_t s
     if (want > 0x7fffffffull) return (int)hipErrorInvalidValue;
     const uint32_t blocks = (uint32_t)want;
     hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, stream, (const RawF4 *)src, (RawF4 *)dst, n16);
+    return (int)hipGetLastError();
+}
+
+// `waves_per_simd` waves on every SIMD of the device: workgroups of four waves (one per SIMD of a CU), and so much LDS
+// asked for per workgroup (64 KB at most) that no more than waves_per_simd of them fit the 160 KB of a CU; the grid holds
+// just that many for every CU.  With one wave per SIMD two workgroups would fit; the dispatcher spreads a grid of one
+// workgroup per CU, and the per-wave clock counts the kernel returns show whether a wave had its SIMD to itself.
+int launch_valu_rate(int mix, int waves_per_simd, int compute_units, uint32_t iterations, float *sink, unsigned long long *cycles, hipStream_t stream) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || compute_units < 1) return (int)hipErrorInvalidValue;
+    uint32_t lds = (160u * 1024u / (uint32_t)waves_per_simd) & ~1023u;
+    if (lds > 64u * 1024u) lds = 64u * 1024u;
+    void (*kernel)(uint32_t, float, float *, unsigned long long *) = mix == 0 ? k_valu_rate<0> : k_valu_rate<1>;
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)(compute_units * waves_per_simd)), dim3(256), lds, stream, iterations, 0.5f, sink, cycles);
     return (int)hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ int cpt_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
 int cpt_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
 int cpt_memset(void *d_dst, int value, size_t bytes);
 int cpt_synchronize(void);
+int cpt_memory_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo of the current device */
 
 /* ---- (1) LBVH builder ------------------------------------------------------------------------
  * Replaces: void kernel::BuildAccel(AccelNode *nodes, Bbox *bboxes, Bbox merged_bbox,
@@ -61,8 +62,9 @@ int cpt_build_accel(void *d_nodes, void *d_bboxes, const float merged_bbox[8], u
 int cpt_build_accel_ex(void *d_nodes, void *d_bboxes, const float merged_bbox[8], uint32_t num_primitives, uint64_t *d_keys_out,
                        uint32_t *d_parents_out, float *stage_ms);
 
-/* cpt_build_accel for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  No counterpart in the reference, whose BuildAccel allocates and frees two temporaries per
+/* cpt_build_accel for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+ * must not disturb the allocator's state).  It enqueues on the null stream and waits for the build, so it is not for
+ * use under stream capture.  No counterpart in the reference, whose BuildAccel allocates and frees two temporaries per
  * call (src/kernels/accel/accel_build.cu:187-199).  Same arguments, same in-place result, returns after the build has
  * completed; all scratch (keys, the copy of the leaf boxes, exchange words, digit counts) lives in one device array of
  * 60 MiB inside the library, which every GPU the library runs on holds until the process ends.  Calls no hipMalloc /
@@ -283,6 +285,9 @@ typedef struct cpt_comm cpt_comm;
 int cpt_comm_unique_id(uint8_t id[128]);
 cpt_comm *cpt_comm_create(const uint8_t id[128], int rank, int world);       /* collective over all ranks; NULL on failure */
 void cpt_comm_destroy(cpt_comm *c);
+/* What RCCL reports about the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice): a measurement can state
+ * that the reduce ran over that many ranks instead of assuming it.  Any pointer may be NULL. */
+int cpt_comm_census(const cpt_comm *c, int *ranks, int *rank, int *device);
 int cpt_tracer_reduce_film(cpt_tracer *t, cpt_comm *c, int root, int finish);
 
 /* One process, one host thread per shard (what `cuda-pathtracer --gpus N` runs): shard i renders on HIP device
@@ -316,6 +321,15 @@ int cpt_selftest_division(uint64_t pairs, uint32_t seed, uint64_t *mismatches);
  * times with a plain streaming kernel and reports (bytes read + bytes written) per second, the
  * rate to set next to the nominal HBM peak when judging the build and traversal kernels. */
 int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s);
+
+/* Device measurement with no counterpart in the reference: the rate at which the device issues vector instructions.
+ * Every SIMD of every CU runs `waves_per_simd` (1 to 8) waves of independent wave64 instructions that touch no memory:
+ * mix 0 = v_fma_f32 only, mix 1 = the kinds a box test is made of (subtract, multiply, compare + select, max, min).
+ * ginst_per_s receives 1e9 wave64 instructions per second over the whole device -- the ceiling the instruction counts of
+ * the traversal kernels are set against; cycles_per_inst (optional) the shader-clock cycles one wave spent per instruction
+ * (waves_per_simd of them share a SIMD, so the SIMD issues one every cycles_per_inst / waves_per_simd); shader_mhz
+ * (optional) the clock the device held meanwhile. */
+int cpt_valu_issue_rate(int mix, int waves_per_simd, double *ginst_per_s, double *cycles_per_inst, double *shader_mhz);
 
 /* Standalone OpenEXR writer used by Film::SaveTo (src/pathtracer/film.cpp:61-68). */
 int cpt_write_exr(const char *path, const float *rgba, uint32_t width, uint32_t height);

@@ -64,6 +64,7 @@ def test_one_rank_per_process_interface(cpt):
     W, H, depth, total = 64, 64, 5, 12
     ref, _ = single_render(cpt, scene, W, H, depth, total)
     comm = cpt.Comm(cpt.Comm.unique_id(), 0, 1)
+    assert comm.census() == (1, 0, 0)                     # what RCCL itself reports: one rank, rank 0, on device 0
     tr = cpt.Tracer(scene, W, H, max_depth=depth)
     tr.set_integrator(3)
     tr.build_buffers()

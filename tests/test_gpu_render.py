@@ -490,3 +490,76 @@ def test_two_level_records_give_the_same_image(cpt):
         assert np.array_equal(film, ref), key
         assert work[key][:2] == work[(0, 4)][:2], key
         assert (work[key][2] == work[(0, 4)][2]) if key[0] == 0 else (work[key][2] < 0.62 * work[(0, 4)][2]), key
+
+
+def test_render_entry_point_refuses_a_scene_without_lights(cpt):
+    """PathTracer::Update returns early for a scene without an emissive object (/root/reference/src/pathtracer/pathtracer.cpp:27-29);
+    the kernel-level entry, which has no film of its own to leave untouched, reports the state instead of launching a kernel
+    that would index an empty light table.  The other entry points render nothing, as Update does."""
+    objs, cam = synthetic_scene("heightfield", 2000)
+    sc = cpt.Scene()
+    o = objs[0]                                            # the mesh alone, the emissive quad left out
+    sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+    W, H = 48, 32
+    sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
+    tr = cpt.Tracer(sc, W, H, max_depth=4).build_buffers()
+    assert cpt.lib.cpt_tracer_num_lights(tr.h) == 0
+    out = cpt.DeviceArray((H, W, 4), np.float32)
+    out.zero()
+    p = cpt.RenderParams(tr.h, out.ptr, W, H, 1, 4, 0)
+    assert cpt.lib.cpt_path_tracer_render(C.byref(p)) == -1
+    assert b"emissive" in cpt.lib.cpt_last_error()
+    assert not out.to_host().any()
+    tr.update(3)
+    tr.render_samples(1, 2, True)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 0 and not tr.film().any()
+    # first hits need no light
+    inst, prim, _, _ = tr.first_hit(tr.camera_rays(W, H))
+    assert (inst != 0xFFFFFFFF).any()
+
+
+def test_kernel_level_render_leaves_the_accumulation_of_an_edited_scene_to_the_next_update(cpt):
+    """cpt_path_tracer_render after a material edit renders with the new material but does not clear the tracer's film or
+    reset its sample counter; the next update does, as after any edit."""
+    objs, cam = cornell(glass=True)
+    W, H = 40, 40
+    sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=4)
+    tr.update(4)
+    before = tr.film()
+    m = objs[0]["material"].copy()
+    m[3:6] = [0.1, 0.9, 0.2]
+    sc.set_material(0, m)
+    out = cpt.DeviceArray((H, W, 4), np.float32)
+    out.zero()
+    tr.render_one(out.ptr, W, H, 1, max_depth=4)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 4
+    assert np.array_equal(tr.film().view(np.uint32), before.view(np.uint32))
+    tr.update(2)
+    assert cpt.lib.cpt_tracer_current_spp(tr.h) == 2
+    objs2 = [dict(o) for o in objs]
+    for o in objs2:
+        if np.array_equal(o["material"], objs[0]["material"]):
+            o["material"] = m
+    ref, _ = OracleScene(objs2, cam).render(W, H, 1, 3, 4)
+    compare(tr.film(), ref)
+
+
+def test_sums_rendered_into_the_films_own_pointer_are_followed_by_correct_means(cpt):
+    """The film's device pointer handed out, the accumulation reset, sums rendered through that pointer (alpha becomes a
+    sample count) and then running-mean samples in launches of several samples: the launch must not take the alpha for
+    its turn counter.  Ends, and equals the same sequence with one sample per launch."""
+    objs, cam = cornell(glass=True)
+    W, H = 48, 48
+    films = []
+    for per_launch in (1, 8):
+        sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=4)
+        tr.set_integrator(5)
+        tr.set_samples_per_launch(per_launch)
+        ptr = cpt.lib.cpt_tracer_film_device_ptr(tr.h)
+        tr.reset()
+        tr.render_samples(1, 3, True, ptr, W, H)
+        tr.synchronize()
+        assert np.all(tr.film()[..., 3] == 3.0)
+        tr.update(6)
+        films.append(tr.film())
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))

@@ -176,9 +176,12 @@ def test_material_to_bsdf_rules():
     assert np.isclose(out[11], (n + 2) / (4 * np.pi * (2 - 2.0 ** (-n / 2))), rtol=1e-6)
 
 
-@pytest.mark.skipif(ref_lib() is None, reason="oracle/_ref/libref.so not built (needs /root/reference)")
 def test_oracle_equals_reference_live():
-    R, L = ref_lib(), oracle()
+    # looked for when the test runs, not when it is collected: a run that deselects this test never maps the library
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref/libref.so not built (needs /root/reference)")
+    L = oracle()
     sizes = np.zeros(8, np.uint32)
     R.ref_sizes(sizes)
     assert [int(x) for x in sizes[:4]] == [KNOWN["struct_sizes"][k] for k in ("Bbox", "AccelNode", "Ray", "Bsdf")]

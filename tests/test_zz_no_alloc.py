@@ -39,6 +39,27 @@ def test_noalloc_build_equals_the_allocating_build_twice_in_a_row(cpt):
         assert np.array_equal(got_boxes.view(np.uint32), ref_boxes.view(np.uint32)), f"{kind} {n}: boxes differ bitwise"
 
 
+def test_noalloc_build_takes_no_device_memory(cpt):
+    """Free device memory reads the same before and after calls of the entry point (its buffers are the caller's and the
+    library's fixed array), for a size it has seen and for one it has not."""
+    cpt.require_device()
+    sizes = (70000, 70000, 300001)
+    inputs = []
+    for n in sizes:
+        boxes, merged = case("soup", n, 11)
+        host = np.zeros((2 * n - 1, 8), np.float32)
+        host[n - 1:] = boxes
+        inputs.append((cpt.DeviceArray.from_host(host), cpt.DeviceArray((2 * n - 1, 2), np.uint32), np.ascontiguousarray(merged, dtype=np.float32), n))
+    d_boxes, d_nodes, merged, n = inputs[0]
+    cpt.check(cpt.lib.cpt_build_accel_noalloc(d_nodes.ptr, d_boxes.ptr, merged, n))       # first call on this device: the array's address is looked up
+    cpt.check(cpt.lib.cpt_synchronize())
+    free_before, _ = cpt.memory_info()
+    for d_boxes, d_nodes, merged, n in inputs[1:]:
+        cpt.check(cpt.lib.cpt_build_accel_noalloc(d_nodes.ptr, d_boxes.ptr, merged, n))
+        free_after, _ = cpt.memory_info()
+        assert free_after == free_before, f"{n} primitives: free device memory moved by {free_before - free_after} bytes"
+
+
 def test_noalloc_build_rejects_inputs_beyond_its_array(cpt):
     cpt.require_device()
     n = cpt.lib.cpt_build_accel_noalloc_max_primitives() + 1
