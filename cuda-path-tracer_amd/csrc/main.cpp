@@ -2,11 +2,13 @@
 // executable on its headless path (src/main.cpp:18-48, 121-130):
 //   cuda-pathtracer <obj> <json|xml> [--ui 0|1] [--max-depth N] [--max-spp N] [--output|-o NAME]
 //                   [--bsdf-type lambert|phong|blinn-phong|microfacet]
-// plus three flags of this build: --gpus N (render on N GPUs of this node: replicated scene, samples split,
-// one RCCL sum-reduce), --shards N (logical shards, default = gpus; shard i runs on GPU i mod gpus) and
-// --scene-cache 0|1 (keep a binary copy of the parsed scene next to the .obj).  There is no interactive
+// plus four flags of this build: --gpus N (render on N GPUs of this node: replicated scene, samples split,
+// one RCCL sum-reduce), --shards N (logical shards, default = gpus; shard i runs on GPU i mod gpus),
+// --scene-cache 0|1 (keep a binary copy of the parsed scene next to the .obj) and --timings 0|1 (print the seconds the
+// scene load, the device build, the first sample and the whole run took).  There is no interactive
 // window: --ui is accepted, 1 only prints a note.  Writes NAME.exr.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <filesystem>
 #include <functional>
@@ -31,6 +33,7 @@ struct Options {
     int gpus = 1;
     int shards = 0;            // 0 = one per GPU
     int scene_cache = 0;
+    int timings = 0;
 };
 
 struct Flag {
@@ -49,6 +52,7 @@ const std::vector<Flag> &Flags() {
         {{"--gpus"}, "GPUs of this node to render on (default 1): scene replicated, samples split, one RCCL reduce", [](Options &o, const char *v) { o.gpus = std::atoi(v); }},
         {{"--shards"}, "sample blocks rendered side by side (default: one per GPU); shard i runs on GPU i mod gpus", [](Options &o, const char *v) { o.shards = std::atoi(v); }},
         {{"--scene-cache"}, "1: read and keep <obj>.cptcache, a binary copy of the parsed scene (default 0)", [](Options &o, const char *v) { o.scene_cache = std::atoi(v); }},
+        {{"--timings"}, "1: print the seconds spent loading the scene, building on the device, on the first sample and in all (default 0)", [](Options &o, const char *v) { o.timings = std::atoi(v); }},
     };
     return table;
 }
@@ -109,6 +113,8 @@ int main(int argc, char **argv) {
     if (extension != ".json" && extension != ".xml") return Complain("unknown extra file extension '" + extension + "'");
     if (options.gpus < 1 || options.shards < 0) return Complain("--gpus needs a positive number, --shards a non-negative one");
 
+    const auto started = std::chrono::steady_clock::now();
+    auto seconds_since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count(); };
     try {
         Scene scene{};
         bool from_cache = false;
@@ -119,6 +125,7 @@ int main(int argc, char **argv) {
         const bool extra_ok = extension == ".json" ? LoadJsonScene(scene, extra_path) : LoadXmlScene(scene, extra_path);
         if (!extra_ok) return Complain("failed to load " + extension.substr(1) + " file '" + extra_path.string() + "'");
         if (options.ui) std::cout << "note: no interactive window in this build, rendering headless" << std::endl;
+        if (options.timings) std::cout << "timing: scene loaded after " << seconds_since_start() << " s" << (from_cache ? " (from the cache)" : "") << std::endl;
 
         auto camera_object = scene.FirstObjectWith<CameraComponent>();
         if (!camera_object) return Complain("the scene has no camera");
@@ -134,9 +141,15 @@ int main(int argc, char **argv) {
             path_tracer->SetIntegrator(3);                // bounce-loop kernel by scene size; the image does not depend on it
             path_tracer->SetCaptureName(options.output);
             path_tracer->BuildBuffers();
+            if (options.timings) std::cout << "timing: device buffers and BVHs built after " << seconds_since_start() << " s" << std::endl;
+            if (options.timings && max_spp != 0) {       // the first sample on its own, so that its end can be reported
+                path_tracer->UpdateMany(1);
+                path_tracer->Synchronize();
+                std::cout << "timing: first sample finished after " << seconds_since_start() << " s" << std::endl;
+            }
             // The reference renders one sample per scene.Update() and reports every 16th (src/main.cpp:123-128);
             // the samples between two reports are asked for together, which leaves the same film.
-            for (uint32_t done = 0; done < max_spp;) {
+            for (uint32_t done = (options.timings && max_spp != 0) ? 1 : 0; done < max_spp;) {
                 const uint32_t batch = std::min(16u - done % 16u, max_spp - done);
                 path_tracer->UpdateMany(batch);
                 done += batch;
@@ -160,7 +173,9 @@ int main(int argc, char **argv) {
             if (tracer.NumLights() != 0) tracer.Render(max_spp, 1, ReportProgress, &reported);
             std::cout << shards << " shards on " << tracer.NumDevices() << " GPU(s): " << tracer.LastRenderMs() << " ms" << std::endl;
         }
+        if (options.timings) std::cout << "timing: rendered after " << seconds_since_start() << " s" << std::endl;
         if (!film.SaveTo(exr_name.c_str())) return Complain("failed to write '" + exr_name + "'");
+        if (options.timings) std::cout << "timing: image written after " << seconds_since_start() << " s" << std::endl;
     } catch (const std::exception &e) {
         return Complain(std::string("error: ") + e.what());
     }

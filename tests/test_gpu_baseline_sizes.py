@@ -130,3 +130,24 @@ def test_full_size_film_of_the_10m_configuration(cpt, depth):
     assert np.all(sums[..., 3] == float(S))
     assert np.allclose(sums[..., :3] / S, films[0][..., :3], rtol=1e-5, atol=1e-6)
     assert films[0][..., :3].mean() > 1e-3
+
+
+def test_scene_files_of_the_10m_configuration_end_to_end(tmp_path):
+    """The 10M-triangle scene as files (/root/reference/src/scene/loader.cpp:144-260, src/scene/mesh.cpp:84-149): about
+    1.2 GB of .obj text written from the seeded generator, rendered by the executable twice with --scene-cache 1 (the
+    first run parses the text, the second reads the binary copy), both images bit for bit the render of the same triangles
+    handed over in memory (scripts/ingest_scene.py asserts that and reports times and peak memory)."""
+    import json
+    import subprocess
+    import sys
+    _live.clear()
+    gc.collect()
+    out = tmp_path / "ingest.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ingest_scene.py"), "heightfield", "10000000", str(out), "1920", "1080", "2", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.load(open(out))
+    assert rep["triangles"] > 9_990_000 and rep["obj_mib"] > 1000
+    assert rep["image_of_parsed_scene_equals_in_memory_scene_bitwise"] and rep["image_of_cached_scene_equals_in_memory_scene_bitwise"]
+    assert not rep["first_run_parses_the_text"]["from_cache"] and rep["second_run_reads_the_cache"]["from_cache"]
+    assert rep["lit_pixel_fraction"] > 0.5

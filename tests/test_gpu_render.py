@@ -537,11 +537,12 @@ def test_kernel_level_render_leaves_the_accumulation_of_an_edited_scene_to_the_n
     tr.update(2)
     assert cpt.lib.cpt_tracer_current_spp(tr.h) == 2
     objs2 = [dict(o) for o in objs]
-    for o in objs2:
-        if np.array_equal(o["material"], objs[0]["material"]):
-            o["material"] = m
-    ref, _ = OracleScene(objs2, cam).render(W, H, 1, 3, 4)
+    objs2[0]["material"] = m
+    osc = OracleScene(objs2, cam)
+    ref, _ = osc.render(W, H, 1, 3, 4)
     compare(tr.film(), ref)
+    one, _ = osc.render(W, H, 1, 2, 4)                     # the kernel-level call already rendered with the edited material
+    compare(out.to_host(), one)
 
 
 def test_sums_rendered_into_the_films_own_pointer_are_followed_by_correct_means(cpt):
