@@ -1,6 +1,8 @@
 """Turns the per-kernel sums of one set of counter passes (scripts/pmc_passes.sh) into an entry of
 profiles/r02_counters.json, the file bench.py reads counter-derived values from.
-usage: python scripts/pmc_to_json.py <pmc outdir> <kernel substring> <entry key> <samples per dispatch> <json file> [note]
+usage: python scripts/pmc_to_json.py <pmc outdir> <kernel substring> <entry key> <samples per dispatch | run:N> <json file> [note]
+With run:N the counters of ALL matching dispatches of the run are summed and divided by the N samples the run rendered
+(a kernel sequence that takes several dispatches per sample, such as the wavefront integrator's).
 Derivations (per dispatch, then per sample):
   hbm bytes     (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte read requests at
                 64 bytes, so wide reads count at half their bytes (the raw value is kept next to it)
@@ -9,7 +11,9 @@ Derivations (per dispatch, then per sample):
   l1_hit        1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES;  l2_hit = TCC_HIT / (TCC_HIT + TCC_MISS)"""
 import collections, csv, glob, json, os, re, sys
 
-out, want, key, samples, path = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5]
+out, want, key, path = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[5]
+whole_run = sys.argv[4].startswith("run:")
+samples = float(sys.argv[4][4:]) if whole_run else float(sys.argv[4])
 note = sys.argv[6] if len(sys.argv) > 6 else ""
 tot = collections.defaultdict(float)
 calls = collections.defaultdict(int)
@@ -23,8 +27,13 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         calls[r["Counter_Name"]] += 1
 if not tot:
     raise SystemExit(f"no dispatch of a kernel matching '{want}' under {out}")
-v = {c: tot[c] / calls[c] for c in tot}           # per dispatch
-entry = {"kernel": want, "kernels_matched": sorted(names)[:4], "samples_per_dispatch": samples, "dispatches_per_pass": min(calls.values()), "note": note}
+if whole_run:
+    v = dict(tot)                                  # the run's totals stand for one "launch" of `samples` samples
+    entry = {"kernel": want, "kernels_matched": sorted(names)[:8], "samples_per_dispatch": None, "samples_in_the_run": samples,
+             "dispatches_per_pass": min(calls.values()), "note": note}
+else:
+    v = {c: tot[c] / calls[c] for c in tot}           # per dispatch
+    entry = {"kernel": want, "kernels_matched": sorted(names)[:4], "samples_per_dispatch": samples, "dispatches_per_pass": min(calls.values()), "note": note}
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
     entry["fetch_kb_raw_per_launch"] = v["FETCH_SIZE"]
     entry["write_kb_per_launch"] = v["WRITE_SIZE"]
