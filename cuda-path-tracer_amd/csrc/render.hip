@@ -169,16 +169,42 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 
 // The persistent kernel again, but a wave no longer waits for its slowest ray before it shades:
 // traversal state stays in registers across the shading step (flow_lane.h), lanes with a finished
-// extension ray are shaded and given their next rays as soon as they are three eighths of the
+// extension ray are shaded and given their next rays as soon as they are five eighths of the
 // wave's live lanes, and shadow rays run in the same loop as extension rays.  Lanes that enter the loop at
 // different times vote less often for the same kind of step, which costs more than the idle lanes
 // did on a scene that sits in the vector L1 (cornell-box-glass: 1.66 against 1.42 ms per sample);
 // with long rays through a large BVH it wins (heightfield 10M: 248 -> 395 Mpaths/s, soup 1M 73 -> 104).
 // Four waves per SIMD and 16 LDS stack entries for every scene: five waves measured the same, six spill.
-constexpr int kFlowWaves = 4;          // 3 waves (168 registers, nothing spilled) and 2 waves measured: heightfield 10M 424 and 302 against 468 Mpaths/s on binary records, 3 waves 525 against 545 on two-level ones (soup 1M 197 against 217): residency beats spills here
-#ifndef FLOW_NUM
-#define FLOW_NUM 3
+// The kernel's shape and thresholds; each can be overridden on the compiler's command line for an A/B build
+// (scripts/build_variant.sh).  Measured on two-level records, heightfield 10M 3840 x 2160 depth 5, Mpaths/s:
+//   waves per SIMD / LDS stack entries   4 / 16: 549   5 / 12: 404 (spills)   4 / 12: no gain   (3 waves, no spills: 525)
+//   shade threshold in eighths           2: 524   3: 549   4: 563   5: 570   6: 551
+//   leaf weight of the step vote         1: 568   2: 576   3: 571   4: 563   6: 536   (each with threshold 4)
+//   trips between looks at ended rays    8: 535   16: 549   32: 561 with threshold 4, where 16 gives 563
+//   threshold 5 with weight 3: 575 (soup 1M 219 against 220, heightfield 1M 670 against 648); with weight 2: 578, but soup 1M 211
+// Two things that were built, measured on the same scene and taken out again: asking for the record of a subtree when it goes
+// on the stack (a four-byte load into a scrap area of LDS, so that the fetch at pop time finds the line in the caches): 493
+// against 550 -- loads return in order, so the next record waits for the touch issued before it; and shading a hit from one
+// 64-byte surface record per triangle slot (normals and texture coordinates as first value + differences, next to the
+// triangle record) instead of three indices and then the vertex attributes: 574 against 576, the same film bit for bit --
+// the fetches of the shading step are not what the kernel waits for.
+#ifndef CPT_FLOW_WAVES
+#define CPT_FLOW_WAVES 4
 #endif
+#ifndef CPT_FLOW_LDS
+#define CPT_FLOW_LDS kLdsStackEntries
+#endif
+#ifndef CPT_FLOW_PERIOD
+#define CPT_FLOW_PERIOD 15u
+#endif
+#ifndef CPT_FLOW_LEAF_WEIGHT
+#define CPT_FLOW_LEAF_WEIGHT 3
+#endif
+#ifndef FLOW_NUM
+#define FLOW_NUM 5
+#endif
+constexpr int kFlowWaves = CPT_FLOW_WAVES;
+constexpr int kFlowLeafWeight = CPT_FLOW_LEAF_WEIGHT;      // this kernel's weight of a lane at a triangle or an instance in the step vote (Traversal::vote_step)
 constexpr int kFlowShadeEighths = FLOW_NUM;      // shade when the lanes waiting for it are this many eighths of the wave's live lanes
 
 #ifdef CPT_STEP_STATS
@@ -186,11 +212,11 @@ __device__ unsigned long long g_step_stats[18];      // development build: step 
 #endif
 template <bool MAPS, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
-    __shared__ uint2 s_stack[kLdsStackEntries * kTraceBlock];
+    __shared__ uint2 s_stack[CPT_FLOW_LDS * kTraceBlock];
     __shared__ unsigned long long s_cnt[5];
     __shared__ float s_next[4 * kTraceBlock];      // per lane: reciprocal direction and flags of the extension ray that follows its shadow ray
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<kLdsStackEntries, kLeafWeightLargeScene, FAST, WIDE> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
+    TraceStackT<CPT_FLOW_LDS, kFlowLeafWeight, FAST, WIDE> st(s_stack, spill_entries, sc.counters);      // the build for large scenes
     LaneCounters cnt;
 #ifdef CPT_STEP_STATS
     StepStats stats;
@@ -286,7 +312,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
             const bool shadow = s.has_shadow;
             auto world = [&](V3 &ow, V3 &dw) { ow = s.l.ro; dw = shadow ? s.shadow_dir : s.l.rd; };
             const bool moved = t.step(sc, st, cnt, world, shadow);
-            if (moved && (trip & 15u) != 15u) continue;
+            if (moved && (trip & CPT_FLOW_PERIOD) != CPT_FLOW_PERIOD) continue;
             if (!t.walking() && (s.has_shadow || s.has_ext)) ray_ended();
             const int walking = lanes_in(__ballot(t.walking()));
             const int waiting = lanes_in(__ballot(!t.walking() && (s.l.alive || !fetch.exhausted)));

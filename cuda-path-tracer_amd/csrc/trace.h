@@ -276,7 +276,10 @@ __device__ inline bool tri_test_or_tie(const TriRecord *rec, V3 o, V3 d, float t
 constexpr uint32_t kNoNode = 0xffffffffu;
 // triangle tests a lane may make in one trip on two-level records (see Traversal::vote_step; 1, 2 and 4 measured: Cornell box
 // 1546 / 1576 / 1565 Mpaths/s, heightfield 10M 535 / 550 / 529; the ordered batch queries on binary records lose 15 % with 2)
-constexpr int kLeafRun = 2;
+#ifndef CPT_LEAF_RUN
+#define CPT_LEAF_RUN 2
+#endif
+constexpr int kLeafRun = CPT_LEAF_RUN;
 
 // Ordered traversal over a two-level record: the (up to four) slots that are hit, nearest first.  On return r[0] is
 // the slot to walk next (kNoNode: none was hit) and r[1..3] the ones to push, r[3] first; slots that were missed or
@@ -296,7 +299,10 @@ __device__ inline void order_slots(float t[4], uint32_t r[4]) {
 // the node walkers holds its ray back for many trips.  Measured with the weights 1, 2, 3, 4, 8: on scenes whose
 // rays diverge 4 is best (soup 1M 102 -> 126 Mpaths/s, heightfield 10M 396 -> 428), on the Cornell box and on
 // coherent camera rays 1 is (4 costs 2-4 % there), so the kernel builds for large scenes use 4, the others 1.
-constexpr int kLeafWeightLargeScene = 4;
+#ifndef CPT_LEAF_WEIGHT
+#define CPT_LEAF_WEIGHT 4
+#endif
+constexpr int kLeafWeightLargeScene = CPT_LEAF_WEIGHT;
 
 // Traversal state of one lane: where it stands (`cur`: internal node, triangle slot, instance
 // leaf, or kNoNode when the ray is finished), its stack window and the ray in world and instance

