@@ -321,6 +321,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lbvh", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the variants, primary_rays and cornell_box_glass blocks")
+    ap.add_argument("--single-rank-rccl", action="store_true",
+                    help="with --gpus 1: run the N>1 code path on one rank -- process group over nccl, the library's RCCL communicator of one rank, "
+                         "samples rendered as sums and passed through ncclReduce (what a one-GPU box can execute of the sharded path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="run the N>1 code path with every rank on GPU 0 and the reduce over gloo (functional rehearsal, not a measurement: "
                          "RCCL does not accept two ranks on one device)")
@@ -336,9 +339,13 @@ def main():
     rehearse = args.rehearse_on_one_gpu
     if rehearse:
         local_rank = 0
+    sharded = world > 1 or args.single_rank_rccl        # the one-process-per-GPU path: sums, one reduce to rank 0
+    if args.single_rank_rccl and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if sharded:
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world, **({} if rehearse else {"device_id": device}))
 
     cpt = load_cpt()
@@ -354,7 +361,7 @@ def main():
     comm = None
     comm_note = ""
     rccl_census = None
-    if world > 1 and not rehearse:
+    if sharded and not rehearse:
         # the communicator id travels by torch.distributed; everything after that is the library's own RCCL use
         ident = [None]
         if rank == 0:
@@ -381,19 +388,19 @@ def main():
             comm_note = "FALLBACK: library communicator unavailable (" + (comm_note or "another rank failed") + "); films reduced by torch.distributed, not a measurement of the library's RCCL path"
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     def all_max(x):
-        if world == 1:
+        if not sharded:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def all_sum(counters):
-        if world == 1:
+        if not sharded:
             return dict(counters)
         t = torch.tensor([counters[k] for k in COUNTER_KEYS], dtype=torch.int64, device=torch.device("cpu") if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -405,12 +412,12 @@ def main():
         tracer.render_samples(begin, count, True)
         if comm is not None:
             tracer.reduce_film(comm, root=0, finish=finish)
-        elif world > 1 and rehearse:                    # rehearsal: same blocks, the sum over gloo on the host
+        elif sharded and rehearse:                      # rehearsal: same blocks, the sum over gloo on the host
             tracer.synchronize()
             host = torch.from_numpy(tracer.film())
             sharding.reduce_sum_to_root(host, dst=0)
             return host.numpy()
-        elif world > 1:                                 # fallback only: the films as torch tensors, summed by torch.distributed
+        elif sharded:                                   # fallback only: the films as torch tensors, summed by torch.distributed
             tracer.synchronize()
             dev = torch.from_numpy(tracer.film()).to(device)
             sharding.reduce_sum_to_root(dev, dst=0)
@@ -423,7 +430,7 @@ def main():
         tracer.synchronize()
         tracer.reset_counters()
         reduced = None
-        if world == 1:
+        if not sharded:
             # the reference's own path: PathTracer::Update, one sample per call, running mean in the film
             tracer.reset()
             barrier()
@@ -474,7 +481,7 @@ def main():
     integrator = args.integrator if args.integrator != 3 else (4 if scene_triangles >= 65536 else 5)     # what mode 3 resolves to in the library
     per_launch = samples_per_launch if integrator in (4, 5) else 1
 
-    if world == 1:
+    if not sharded:
         tracer.update(WU)
     else:
         sharded_render(tracer, 1, WU)
@@ -484,7 +491,7 @@ def main():
     if rank == 0:
         paths = W * H * K * world
         kernel_name = KERNEL_OF[integrator]
-        if world == 1:
+        if not sharded:
             sharding_note = "replicas only"
         elif comm is not None:
             sharding_note = (f"{world} x disjoint blocks of {K} sample indices, one ncclReduce of the {W * H * 16 / 1e6:.1f} MB films issued by the library; "
@@ -493,7 +500,7 @@ def main():
             sharding_note = f"{world} ranks rehearsed on one GPU, sum over gloo"
         else:
             sharding_note = comm_note
-        valid = world == 1 or comm is not None or rehearse
+        valid = not sharded or comm is not None or rehearse
         result = {
             "metric": f"Mpaths/s per node, {args.workload} {W}x{H} max-depth {max_depth} (Mrays/s, LBVH build ms @1M/10M, cornell-box-glass alongside)",
             "value": round(paths / elapsed / 1e6, 3) if valid else None,
@@ -526,7 +533,7 @@ def main():
         m = measured_counters(f"{COUNTER_KERNEL[integrator]}/{args.workload}/{args.traversal}") if (W, H) == (dW, dH) and max_depth == ddepth else None
         roof = roofline_block(kernel_name, alg_bytes, avg_ms, samples_in_launch, m, valu_peak)
         roof["launches"] = launches
-        if world > 1:
+        if sharded:
             roof["note_multi_gpu"] = "rank 0's launches; avg_launch_ms includes this rank's share of the reduce"
         result["roofline"] = roof
 
@@ -548,7 +555,7 @@ def main():
                 tracer.set_max_depth(depth)
                 tracer.set_integrator(mode)
                 tracer.set_traversal(trav)
-                if world == 1:
+                if not sharded:
                     tracer.reset()
                     tracer.update(2)
                 else:
@@ -627,7 +634,7 @@ def main():
             result["cpu_baseline_other_configs"] = others
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if sharded:
         dist.barrier()
         if comm is not None:
             comm.close()

@@ -4,6 +4,7 @@ the result must equal the single-tracer render up to the order of fp32 additions
 GPUs visible the same tests also spread the shards over them."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -126,3 +127,18 @@ def test_ten_million_triangles_sharded(cpt):
     c = multi.counters()
     assert c["paths"] == W * H * spp and c["rays"] == rc["rays"] and c["stack_overflows"] == 0
     multi.close()
+
+
+def test_bench_runs_its_sharded_path_on_one_rank_with_the_library_communicator(cpt):
+    """bench.py --single-rank-rccl: everything the N > 1 line does that one GPU can execute -- torch's process group over nccl,
+    the library's own RCCL communicator made inside that process from an id, samples rendered as sums, ncclReduce on the
+    tracer's stream, division on the root -- and the line says how many ranks RCCL itself reports."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-rccl", "--workload", "cornell-box-glass", "--steps", "8",
+                        "--warmup", "2", "--width", "256", "--height", "256", "--no-extras", "--no-lbvh", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is not None and line["value"] > 0 and line["n_gpus"] == 1
+    assert line["config"]["rccl_ranks"] == 1 and "RCCL reports 1 ranks" in line["config"]["sharding"]
+    assert "FALLBACK" not in line["config"]["sharding"]
