@@ -98,6 +98,7 @@ public:
     float LastRenderMs() const { return last_ms_; }          // wall time of the last Render, reduce included
     size_t NumShards() const { return shards_.size(); }
     size_t NumDevices() const { return comms_.size(); }
+    int RcclRanks() const { return comms_.empty() ? 0 : comms_.front()->Census().ranks; }      // what ncclCommCount reports
     uint32_t NumLights() const;
     void ReadCounters(unsigned long long out[6]);            // summed over shards
     void ResetCounters();

@@ -171,7 +171,7 @@ int main(int argc, char **argv) {
             tracer.BuildBuffers();
             uint32_t reported = 0;
             if (tracer.NumLights() != 0) tracer.Render(max_spp, 1, ReportProgress, &reported);
-            std::cout << shards << " shards on " << tracer.NumDevices() << " GPU(s): " << tracer.LastRenderMs() << " ms" << std::endl;
+            std::cout << shards << " shards on " << tracer.NumDevices() << " GPU(s): " << tracer.LastRenderMs() << " ms (RCCL communicator of " << tracer.RcclRanks() << " rank(s))" << std::endl;
         }
         if (options.timings) std::cout << "timing: rendered after " << seconds_since_start() << " s" << std::endl;
         if (!film.SaveTo(exr_name.c_str())) return Complain("failed to write '" + exr_name + "'");

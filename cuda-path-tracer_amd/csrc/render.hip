@@ -182,12 +182,15 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 //   leaf weight of the step vote         1: 568   2: 576   3: 571   4: 563   6: 536   (each with threshold 4)
 //   trips between looks at ended rays    8: 535   16: 549   32: 561 with threshold 4, where 16 gives 563
 //   threshold 5 with weight 3: 575 (soup 1M 219 against 220, heightfield 1M 670 against 648); with weight 2: 578, but soup 1M 211
-// Two things that were built, measured on the same scene and taken out again: asking for the record of a subtree when it goes
-// on the stack (a four-byte load into a scrap area of LDS, so that the fetch at pop time finds the line in the caches): 493
-// against 550 -- loads return in order, so the next record waits for the touch issued before it; and shading a hit from one
-// 64-byte surface record per triangle slot (normals and texture coordinates as first value + differences, next to the
-// triangle record) instead of three indices and then the vertex attributes: 574 against 576, the same film bit for bit --
-// the fetches of the shading step are not what the kernel waits for.
+// Two things that were built, measured on the same scene and taken out again.  (1) Asking early for the record of a subtree
+// that waits on the stack, by a four-byte load straight into a scrap area of LDS (no register, nothing to wait for), so
+// that the fetch at pop time finds the line in the caches: when the subtree is pushed 493 against 550 Mpaths/s; for the
+// top of the stack, issued by hand BEHIND the eight loads of the record being visited with the wait written out so that
+// the touch alone stays in flight (loads return in order: a touch holds back every load issued after it until it has
+// arrived itself) 541 against 575.  The next record's loads queue behind a touch that went to memory, and that costs more
+// than the pop saves.  (2) Shading a hit from one 64-byte surface record per triangle slot (normals and texture
+// coordinates as first value + differences, next to the triangle record) instead of three indices and then the vertex
+// attributes: 574 against 576, the same film bit for bit -- the fetches of the shading step are not what the kernel waits for.
 #ifndef CPT_FLOW_WAVES
 #define CPT_FLOW_WAVES 4
 #endif
