@@ -99,6 +99,7 @@ class RenderParams(C.Structure):
 
 _sig("cpt_path_tracer_render", C.c_int, [C.POINTER(RenderParams)])
 _sig("cpt_tracer_film_device_ptr", _vp, [_vp])
+_sig("cpt_tracer_set_query_kernel", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_film_read", C.c_int, [_vp, _f32])
 _sig("cpt_tracer_film_save", C.c_int, [_vp, C.c_char_p])
 _sig("cpt_tracer_first_hit", C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp])
@@ -363,6 +364,10 @@ class Tracer:
     def set_node_records(self, mode):
         """1: two-level node records are built and walked by the exact traversal (default); 0: binary records only.  Before build_buffers."""
         check(lib.cpt_tracer_set_node_records(self.h, mode))
+
+    def set_query_kernel(self, mode):
+        """1: large batches of first-hit queries (exact traversal) run the persistent kernel that refills its lanes; 0 (default): one ray per lane."""
+        check(lib.cpt_tracer_set_query_kernel(self.h, mode))
 
     def set_wavefront_tail(self, bounces):
         check(lib.cpt_tracer_set_wavefront_tail(self.h, bounces))

@@ -487,10 +487,13 @@ int cpt_tracer_first_hit(cpt_tracer *t, const float *d_rays, uint64_t num_rays, 
     if (num_rays == 0) return CPT_OK;
     if (!d_rays || !d_instance || !d_primitive) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: null argument");
     if (t->tracer->NumInstances() == 0) return Fail(CPT_ERR_INVALID, "cpt_tracer_first_hit: build_buffers has not produced any geometry");
-    return Guard([&] {
-        int rc = cpt::launch_first_hit(t->tracer->DeviceSceneForQueries(), d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, t->tracer->Stream());
-        return rc == 0 ? CPT_OK : HipFail((hipError_t)rc, "first_hit");
-    });
+    return Guard([&] { t->tracer->FirstHit(d_rays, num_rays, d_instance, d_primitive, d_t, d_uv); return CPT_OK; });
+}
+int cpt_tracer_set_query_kernel(cpt_tracer *t, int mode) {
+    TRACER_OR_FAIL(t);
+    if (mode < 0 || mode > 1) return Fail(CPT_ERR_INVALID, "cpt_tracer_set_query_kernel: 0 (one ray per lane for the launch) or 1 (persistent, lanes refilled)");
+    t->tracer->SetQueryKernel(mode);
+    return CPT_OK;
 }
 int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint8_t *d_occluded) {
     TRACER_OR_FAIL(t);

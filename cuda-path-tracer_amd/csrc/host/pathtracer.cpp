@@ -581,6 +581,30 @@ void PathTracer::RenderOneSample(float *output, uint32_t width, uint32_t height,
     CPT_HIP(hipStreamSynchronize(stream_));
 }
 
+void PathTracer::FirstHit(const float *d_rays, uint64_t num_rays, uint32_t *d_instance, uint32_t *d_primitive, float *d_t, float *d_uv) {
+    const cpt::SceneDev &sc = DeviceSceneForQueries();
+    if (!query_stream_ || sc.fast_traversal != 0 || num_rays < kStreamQueryRays || num_rays >= 0xffffffc0ull) {
+        rc_check(cpt::launch_first_hit(sc, d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, stream_), "first_hit");
+        return;
+    }
+    if (!query_queue_.Size()) {
+        query_queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
+        query_queue_.Zero(stream_);
+        query_parity_ = 0;
+    }
+    const bool fast = sc.fast_traversal != 0, wide = !fast && sc.wide_nodes != 0, large = sc.large_scene != 0;
+    const int key = (large ? 1 : 0) | (fast ? 2 : 0) | (wide ? 4 : 0);
+    if (key != query_key_) {
+        int device = 0;
+        CPT_HIP(hipGetDevice(&device));
+        query_blocks_ = cpt::first_hit_stream_resident_blocks(device, large, fast, wide);
+        query_key_ = key;
+    }
+    rc_check(cpt::launch_first_hit_stream(sc, d_rays, num_rays, d_instance, d_primitive, d_t, d_uv, query_queue_.TypedGpuData<uint32_t>(), query_parity_,
+                                          (uint32_t)query_blocks_, stream_), "first_hit");
+    query_parity_ ^= 1u;
+}
+
 void PathTracer::Synchronize() {
     if (stream_) CPT_HIP(hipStreamSynchronize(stream_));
 }

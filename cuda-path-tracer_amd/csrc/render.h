@@ -43,6 +43,10 @@ int launch_film_finish(float *film, uint64_t pixels, hipStream_t stream);
 // t and uv may be null.
 int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, hipStream_t stream);
 int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *out, hipStream_t stream);
+// cpt_tracer_first_hit as a persistent kernel whose lanes take a new ray when theirs is finished; `queue` as for launch_render_regen
+int launch_first_hit_stream(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, uint32_t *queue, uint32_t parity,
+                            uint32_t max_blocks, hipStream_t stream);
+int first_hit_stream_resident_blocks(int device, bool large, bool fast, bool wide);
 
 // Camera rays of 1-based sample index spp for every pixel, stored in pixel-index order (row 0 = top).
 int launch_camera_rays(const CameraDev &cam, uint32_t W, uint32_t H, uint32_t spp, float *rays, hipStream_t stream);

@@ -517,6 +517,65 @@ __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWa
     flush_counters(sc, cnt, 0u, s_cnt);
 }
 
+// The same query as a persistent kernel: the grid is what the device holds at once, a wave takes the rays in segments of 64
+// consecutive indices from the per-XCD cursors (SegmentFetch, fetching two segments ahead) and hands new rays to lanes whose
+// ray is finished as soon as kQueryRefillLanes of them are idle, inside the traversal loop, instead of holding every lane
+// until the wave's longest ray is done.  A ray's own sequence of steps is the sequential one either way: same results.
+// It pays for rays that diverge and loses for coherent ones, whatever the refill threshold (measured, exact traversal,
+// Grays/s plain -> persistent: rays from inside the heightfield 10M 1.37 -> 1.78, heightfield 1M 2.00 -> 2.48, soup 1M
+// 0.52 -> 0.66; camera rays 2.99 -> 1.85, 3.01 -> 1.42, 0.86 -> 0.50; the ordered traversal, whose build at eight waves
+// spills, loses everywhere), so the caller asks for it (cpt_tracer_set_query_kernel) and the default stays the plain kernel.
+constexpr int kQueryRefillLanes = 16;      // 16 / 32 / 48 / 60 measured on rays from inside the 10M heightfield: 1.30 / 1.34 / 1.26 / 1.09 x the plain kernel (soup 1M: 1.27 / 1.27 / 1.10 / 0.88)
+template <bool LARGE, bool FAST, bool WIDE>
+__global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_first_hit_stream(SceneDev sc, const float *__restrict__ rays, uint32_t n, uint32_t *__restrict__ inst_out,
+                                                            uint32_t *__restrict__ prim_out, float *__restrict__ t_out, float *__restrict__ uv_out, uint32_t *queue, uint32_t parity) {
+    __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
+    __shared__ unsigned long long s_cnt[5];
+    uint2 spill_entries[kSpillEntries];
+    TraceStackT<kQueryLdsEntries, LARGE ? kQueryLeafWeightLargeScene : 1, FAST, WIDE> st(s_stack, spill_entries, sc.counters);
+    LaneCounters cnt;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t *cursors = queue + parity * kCursorSetWords;
+    zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
+    const uint32_t segments = (n + kSegmentSlots - 1) / kSegmentSlots;
+
+    SegmentFetchT<true> f;
+    Traversal t;
+    bool have = false;
+    uint32_t index = 0;
+    for (;;) {
+        unsigned long long idle = __ballot(!have);
+        if (!f.exhausted && (__popcll(idle) >= kQueryRefillLanes || idle == ~0ull)) {
+            while (idle != 0ull) {
+                if (f.remaining() == 0 && !f.advance(nullptr, cursors, segments, blockIdx.x, lane)) break;
+                const uint32_t rank = __popcll(idle & lt_mask);
+                const uint32_t take = min((uint32_t)__popcll(idle), f.remaining());
+                const uint32_t entry = f.entry(rank);
+                if (!have && rank < take && entry < n) {
+                    index = entry;
+                    const float4 *r = reinterpret_cast<const float4 *>(rays) + 2 * (size_t)index;
+                    const float4 a = r[0], b = r[1];
+                    t.template begin<FAST, WIDE>(sc, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), a.w, b.w, cnt);
+                    have = true;
+                }
+                f.consumed += take;
+                idle = __ballot(!have);
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+        t.template vote_step<false>(sc, st, cnt);
+        if (have && !t.live()) {
+            inst_out[index] = t.found ? t.hit.inst : 0xffffffffu;
+            prim_out[index] = t.found ? t.hit.prim : 0xffffffffu;
+            if (t_out) t_out[index] = t.tmax;
+            if (uv_out) { uv_out[2 * (size_t)index] = t.found ? t.hit.u : 0.0f; uv_out[2 * (size_t)index + 1] = t.found ? t.hit.v : 0.0f; }
+            have = false;
+        }
+    }
+    flush_counters(sc, cnt, 0u, s_cnt);
+}
+
 template <bool LARGE, bool FAST, bool WIDE>
 __global__ void __launch_bounds__(kTraceBlock, WIDE ? kWideQueryWaves : kQueryWaves) k_occlude(SceneDev sc, const float *__restrict__ rays, unsigned long long n, uint8_t *__restrict__ out) {
     __shared__ uint2 s_stack[kQueryLdsEntries * kTraceBlock];
@@ -758,6 +817,33 @@ int launch_first_hit(const SceneDev &sc, const float *rays, uint64_t n, uint32_t
     });
     hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, count, inst, prim, t, uv);
     return (int)hipGetLastError();
+}
+
+using StreamQueryKernel = void (*)(SceneDev, const float *, uint32_t, uint32_t *, uint32_t *, float *, float *, uint32_t *, uint32_t);
+StreamQueryKernel first_hit_stream_kernel(bool large, bool fast, bool wide) {
+    return pick(large, [&](auto L) -> StreamQueryKernel {
+        constexpr bool l = decltype(L)::value;
+        return fast ? k_first_hit_stream<l, true, false> : wide ? k_first_hit_stream<l, false, true> : k_first_hit_stream<l, false, false>;
+    });
+}
+
+// n below 2^32 - 64 (segment numbers are 32 bits); queue: kRegenQueueWords words, zeroed once, parity alternating per launch
+int launch_first_hit_stream(const SceneDev &sc, const float *rays, uint64_t n, uint32_t *inst, uint32_t *prim, float *t, float *uv, uint32_t *queue, uint32_t parity,
+                            uint32_t max_blocks, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n >= 0xffffffc0ull || !queue || max_blocks == 0) return (int)hipErrorInvalidValue;
+    const uint64_t want = (n + kTraceBlock - 1) / kTraceBlock;
+    const uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;
+    StreamQueryKernel kernel = first_hit_stream_kernel(sc.large_scene != 0, sc.fast_traversal != 0, sc.fast_traversal == 0 && sc.wide_nodes != 0);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, rays, (uint32_t)n, inst, prim, t, uv, queue, parity);
+    return (int)hipGetLastError();
+}
+
+int first_hit_stream_resident_blocks(int device, bool large, bool fast, bool wide) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)first_hit_stream_kernel(large, fast, wide), kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return per_cu * cus;
 }
 
 int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *out, hipStream_t stream) {

@@ -317,3 +317,29 @@ def test_two_level_records_walk_the_same_leaves(cpt, scene):
         assert np.array_equal(x.view(np.uint32), y[:50000].view(np.uint32))
     assert (f[2] <= again[2]).all()                           # never a farther hit
     assert cpt.lib.cpt_tracer_set_node_records(wide.h, 2) < 0 and cpt.lib.cpt_tracer_set_node_records(wide.h, -1) < 0
+
+
+def test_persistent_query_kernel_gives_the_same_first_hits(cpt):
+    """cpt_tracer_set_query_kernel(1): lanes take the next ray of the batch when theirs is finished.  Same instance,
+    primitive, distance and barycentrics bit for bit as one ray per lane, for a batch that is not a multiple of a
+    segment, for one below the size at which the persistent kernel takes over, and against the oracle."""
+    objs, cam = synthetic_scene("heightfield", 40000)
+    sc, tr = gpu_scene(cpt, objs, cam, 64, 64)
+    osc = OracleScene(objs, cam)
+    lo, hi = np.float32([0, -0.2, 0]), np.float32([1, 1.2, 1])
+    for n in (70001, 65536, 4099):
+        rays = interior_rays(n, 11 + n, lo, hi)
+        tr.set_query_kernel(0)
+        plain = tr.first_hit(rays)
+        tr.set_query_kernel(1)
+        tr.reset_counters()
+        streamed = tr.first_hit(rays)
+        assert tr.counters()["rays"] == n
+        for a, b in zip(plain, streamed):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        if n == 70001:
+            o_inst, o_prim, o_t, o_uv, _ = osc.first_hit(rays)
+            assert np.array_equal(streamed[0], o_inst) and np.array_equal(streamed[1], o_prim)
+            assert np.array_equal(streamed[2].view(np.uint32), o_t.view(np.uint32)) and np.array_equal(streamed[3], o_uv)
+            assert (o_inst != 0xFFFFFFFF).mean() > 0.2
+    tr.set_query_kernel(0)
