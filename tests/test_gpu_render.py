@@ -564,3 +564,38 @@ def test_sums_rendered_into_the_films_own_pointer_are_followed_by_correct_means(
         tr.update(6)
         films.append(tr.film())
     assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+
+
+def test_film_ordered_by_fences_leaves_the_same_film(cpt):
+    """Launches of several samples order a pixel's samples by hand-placed device-scope accesses (integrate.h:
+    film_accumulate_in_order); libcpt_amd_fences.so is the same library with that order kept by acquire / release instead.
+    Sums (turn words) and running means (count in the alpha) at the Cornell configuration's size, 64 samples in launches of
+    32, rendered by both libraries in separate processes: the same film bit for bit."""
+    fences = os.path.join(os.path.dirname(cpt.LIB_PATH), "libcpt_amd_fences.so")
+    assert os.path.exists(fences), "build it with make -C cuda-path-tracer_amd/csrc"
+    program = (
+        "import hashlib, os, sys\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "from conftest import load_cpt\n"
+        "cpt = load_cpt()\n"
+        "d = os.path.join(%r, 'tests', 'golden', 'scenes', 'cornell-box-glass')\n"
+        "sc = cpt.Scene().load_obj(os.path.join(d, 'cornell-box.obj'), 2).load_json(os.path.join(d, 'cornell-box.json'))\n"
+        "tr = cpt.Tracer(sc, 1024, 1024, max_depth=8)\n"
+        "tr.set_integrator(5); tr.set_samples_per_launch(32); tr.build_buffers()\n"
+        "tr.render_samples(1, 64, True); tr.synchronize()\n"
+        "sums = hashlib.sha256(tr.film().tobytes()).hexdigest()\n"
+        "tr.reset(); tr.update(64)\n"
+        "print(os.path.basename(cpt.LIB_PATH), sums, hashlib.sha256(tr.film().tobytes()).hexdigest(), tr.counters()['paths'])\n"
+    ) % (ROOT, ROOT)
+    lines = []
+    for lib in (None, fences):
+        env = dict(os.environ)
+        env.pop("CPT_AMD_LIBRARY", None)
+        if lib:
+            env["CPT_AMD_LIBRARY"] = lib
+        r = subprocess.run([sys.executable, "-c", program], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        lines.append(r.stdout.strip().splitlines()[-1].split())
+    assert lines[0][0] == "libcpt_amd.so" and lines[1][0] == "libcpt_amd_fences.so"
+    assert lines[0][1:] == lines[1][1:], lines
+    assert int(lines[0][3]) == 1024 * 1024 * 128
