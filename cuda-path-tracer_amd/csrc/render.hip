@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 //   leaf weight of the step vote         1: 568   2: 576   3: 571   4: 563   6: 536   (each with threshold 4)
 //   trips between looks at ended rays    8: 535   16: 549   32: 561 with threshold 4, where 16 gives 563
 //   threshold 5 with weight 3: 575 (soup 1M 219 against 220, heightfield 1M 670 against 648); with weight 2: 578, but soup 1M 211
-// Two things that were built, measured on the same scene and taken out again.  (1) Asking early for the record of a subtree
+// Three things that were built, measured on the same scene and taken out again.  (1) Asking early for the record of a subtree
 // that waits on the stack, by a four-byte load straight into a scrap area of LDS (no register, nothing to wait for), so
 // that the fetch at pop time finds the line in the caches: when the subtree is pushed 493 against 550 Mpaths/s; for the
 // top of the stack, issued by hand BEHIND the eight loads of the record being visited with the wait written out so that
@@ -191,6 +191,10 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
 // than the pop saves.  (2) Shading a hit from one 64-byte surface record per triangle slot (normals and texture
 // coordinates as first value + differences, next to the triangle record) instead of three indices and then the vertex
 // attributes: 574 against 576, the same film bit for bit -- the fetches of the shading step are not what the kernel waits for.
+// (3) The camera rays of a launch traced beforehand by lockstep waves of their own (one per 8 x 8 tile and sample, first hits
+// kept in 16 bytes per pixel slot) with the bounce loop starting every path at its first shading step: 568 against 563 with the
+// branch compiled in and 575 without it; soup 1M 198 against 211 -- camera rays cost this kernel what they cost a lockstep
+// kernel (about 0.32 ns each), and the pass only adds its launch and the registers of one more branch.
 #ifndef CPT_FLOW_WAVES
 #define CPT_FLOW_WAVES 4
 #endif
