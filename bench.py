@@ -156,12 +156,15 @@ def cpu_model():
     return "unknown"
 
 
-def lbvh_timings(cpt, n, seed=12345, repeats=10, sort_variant=0):
+def lbvh_timings(cpt, n, seed=12345, repeats=10, sort_variant=0, kind="soup"):
     """Median device time of the whole build (Morton -> sort -> nodes -> refit) with buffers pre-allocated, after
-    two warm-ups; plus the per-stage split of one extra run (hierarchy = leaf gather + topology + boxes)."""
-    soup = scenes.random_soup(n, seed=seed)
-    boxes, merged = scenes.boxes_of_triangles(soup["positions"], soup["indices"])
-    del soup
+    two warm-ups; plus the per-stage split of one extra run (hierarchy = leaf gather + topology + boxes).  The
+    primitives arrive in random order (kind "soup": every leaf box the hierarchy pass gathers is a memory access of
+    its own) or in the order of a mesh (kind "heightfield": neighbours in the file are neighbours in space)."""
+    mesh = scenes.synthetic_scene(kind, n, seed)[0][0]
+    boxes, merged = scenes.boxes_of_triangles(mesh["positions"], mesh["indices"])
+    n = len(boxes)
+    del mesh
     d_leaf = cpt.DeviceArray.from_host(boxes)
     d_boxes = cpt.DeviceArray((2 * n - 1, 8), np.float32)
     d_nodes = cpt.DeviceArray((2 * n - 1, 2), np.uint32)

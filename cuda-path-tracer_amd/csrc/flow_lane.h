@@ -91,9 +91,9 @@ struct Flow {
                 if (is_node) {                          // two levels per record, as in Traversal::vote_step
                     GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
                     const float4 a0 = load_f4(q, 0), a1 = load_f4(q, 1), a2 = load_f4(q, 2), a3 = load_f4(q, 3);
-                    const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6), b3 = load_f4(q, 7);
+                    const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6);      // the first half's last quad has all four references
                     cnt.nodes++;
-                    const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(b3.x), r3 = __float_as_uint(b3.y);
+                    const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(a3.z), r3 = __float_as_uint(a3.w);
                     if constexpr (FAST) {
                         const float inf = __uint_as_float(0x7f800000u);
                         float t[4];
