@@ -5,7 +5,7 @@
 # the counter-derived values bench.py reads (profiles/r03_counters.json is a copy of <out>/counters.json), then the bench
 # line and rocprofv3 kernel stats of the same command.
 # usage: scripts/profile_round3.sh <tag> [parts]      (results under gpurun_out/<tag>/)
-# parts: any of m (10M megakernel passes), w (10M wavefront passes), c (Cornell box and 1M scenes), b (bench line + kernel stats);
+# parts: any of m (10M megakernel passes), w (10M wavefront passes), l (vector memory pipeline, 10M megakernel and Cornell box), c (Cornell box and 1M scenes), b (bench line + kernel stats);
 # default mwcb.  The counter file is added to, part by part, so the parts can run in separate calls on the same tag... of the
 # same tree: each call starts from the copy kept in profiles/r03_counters.json.
 set -e -o pipefail
@@ -17,8 +17,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 parts=${2:-mwcb}
 J=$out/counters.json
 cp "$root/profiles/r03_counters.json" "$J" 2>/dev/null || rm -f "$J"
-if [[ $parts == *m* ]]; then
 S="python3 scripts/bench_synth.py heightfield 10000000 3840 2160"
+if [[ $parts == *m* ]]; then
 # 10M-triangle heightfield 3840x2160: camera rays (10 + 1 launches of k_first_hit) and 32 samples of k_render_flow per launch
 for trav in 0 1; do
   name=$([ $trav = 0 ] && echo exact || echo fast)
@@ -49,6 +49,15 @@ for depth in 5 -1; do
   echo "10M wavefront depth $depth counters done"
 done
 fi
+if [[ $parts == *l* ]]; then
+# how busy the vector memory pipeline is: text summaries only, nothing bench.py reads
+bash scripts/pmc_l1.sh "$out/l1_hf10m" python3 scripts/bench_synth.py heightfield 10000000 3840 2160 32 5 4 0 32
+python3 scripts/pmc_summary.py "$out/l1_hf10m" k_render_flow > "$out/l1_hf10m_k_render_flow.txt"
+python3 scripts/pmc_summary.py "$out/l1_hf10m" k_first_hit > "$out/l1_hf10m_k_first_hit.txt"
+bash scripts/pmc_l1.sh "$out/l1_cornell" python3 scripts/prof_render.py 128 1024 8 3 0 128
+python3 scripts/pmc_summary.py "$out/l1_cornell" k_render_pool > "$out/l1_cornell_k_render_pool.txt"
+echo "vector memory pipeline counters done"
+fi
 if [[ $parts == *c* ]]; then
 # Cornell box: launches of 128 samples
 bash scripts/pmc_passes.sh "$out/pmc_cornell" python3 scripts/prof_render.py 128 1024 8 3 0 128
@@ -71,7 +80,7 @@ cp "$J" "$out/../r03_counters.json"
 if [[ $parts == *b* ]]; then
   timeout -k 10 600 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
   tail -c 600 "$out/bench.json"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 64 --warmup 4 --no-cpu-baseline --no-lbvh --no-extras > "$out/stats.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-lbvh --no-extras > "$out/stats.log" 2>&1
   find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
   head -4 "$out/kernel_stats.csv" | cut -c1-200
 fi
