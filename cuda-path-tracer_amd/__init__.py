@@ -100,6 +100,7 @@ class RenderParams(C.Structure):
 _sig("cpt_path_tracer_render", C.c_int, [C.POINTER(RenderParams)])
 _sig("cpt_tracer_film_device_ptr", _vp, [_vp])
 _sig("cpt_tracer_set_query_kernel", C.c_int, [_vp, C.c_int])
+_sig("cpt_tracer_set_scene_in_lds", C.c_int, [_vp, C.c_int])
 _sig("cpt_tracer_film_read", C.c_int, [_vp, _f32])
 _sig("cpt_tracer_film_save", C.c_int, [_vp, C.c_char_p])
 _sig("cpt_tracer_first_hit", C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp])
@@ -368,6 +369,10 @@ class Tracer:
     def set_query_kernel(self, mode):
         """1: large batches of first-hit queries (exact traversal) run the persistent kernel that refills its lanes; 0 (default): one ray per lane."""
         check(lib.cpt_tracer_set_query_kernel(self.h, mode))
+
+    def set_scene_in_lds(self, on):
+        """Whether the small-scene bounce loop reads the records from its LDS copy (default) or from memory; returns whether the copy exists and is used."""
+        return check(lib.cpt_tracer_set_scene_in_lds(self.h, 1 if on else 0)) == 1
 
     def set_wavefront_tail(self, bounces):
         check(lib.cpt_tracer_set_wavefront_tail(self.h, bounces))

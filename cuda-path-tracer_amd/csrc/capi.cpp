@@ -495,6 +495,11 @@ int cpt_tracer_set_query_kernel(cpt_tracer *t, int mode) {
     t->tracer->SetQueryKernel(mode);
     return CPT_OK;
 }
+int cpt_tracer_set_scene_in_lds(cpt_tracer *t, int on) {
+    TRACER_OR_FAIL(t);
+    t->tracer->SetSceneInLds(on != 0);
+    return t->tracer->SceneInLds() ? 1 : 0;
+}
 int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, uint8_t *d_occluded) {
     TRACER_OR_FAIL(t);
     if (num_rays == 0) return CPT_OK;

@@ -54,6 +54,7 @@ struct MeshDev {
     uint32_t num_triangles;
     uint32_t pad;
     const PackedNode *wide;     // two-level records: two PackedNode-shaped halves per internal node (lbvh.hip: pack_from_memory), or null
+    uint32_t lds_nodes, lds_tris;     // where this mesh's records lie in SceneDev::lds_scene (16-byte words), when that is set
 };
 
 struct InstanceDev {
@@ -133,7 +134,15 @@ struct SceneDev {
     int large_scene;            // the BVH is far larger than the caches next to the CUs: batch queries use the kernel builds for such scenes
     const PackedNode *top_wide; // the top level in two-level records, or null
     int wide_nodes;             // every BVH of the scene has its two-level records
+    // A scene whose traversal records fit kLdsSceneBytes has them once more in one piece, for kernels that keep them in LDS:
+    // the top level's two-level records, then per mesh its two-level records and its triangle records.  A node record is
+    // kLdsNodeWords 16-byte words here (the seven a visit reads, section "traversal-side layout"), a triangle record three.
+    const float *lds_scene;      // or null
+    uint32_t lds_scene_words;    // 16-byte words in it
+    uint32_t lds_top;      // first word of the top level's records (0)
 };
+constexpr uint32_t kLdsSceneBytes = 6144;
+constexpr uint32_t kLdsNodeWords = 7;
 
 struct RenderParams {
     float *output;              // W*H float4, row 0 = top of the image

@@ -24,6 +24,7 @@ struct Flow {
     RayFrame f;
     const PackedNode *nodes = nullptr;
     const TriRecord *tris = nullptr;
+    uint32_t nodes_at = 0, tris_at = 0;       // the same two as 16-byte word positions in the LDS copy of the records (kernels that hold one)
     Hit hit;
 
     __device__ inline bool walking() const { return cur != kNoNode; }
@@ -52,6 +53,7 @@ struct Flow {
         top_ref = kNoNode;
         in_blas = false; found = false;
         nodes = WIDE ? sc.top_wide : sc.top_nodes;
+        nodes_at = sc.lds_top;
         f.o = ow; f.d = dw; f.r = q.r; f.fast = q.fast;
         world_r = q.r;
         world_fast = q.fast;
@@ -89,9 +91,16 @@ struct Flow {
         if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
             if constexpr (WIDE) {
                 if (is_node) {                          // two levels per record, as in Traversal::vote_step
-                    GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
-                    const float4 a0 = load_f4(q, 0), a1 = load_f4(q, 1), a2 = load_f4(q, 2), a3 = load_f4(q, 3);
-                    const float4 b0 = load_f4(q, 4), b1 = load_f4(q, 5), b2 = load_f4(q, 6);      // the first half's last quad has all four references
+                    float4 a0, a1, a2, a3, b0, b1, b2;       // the first half's last word has all four references; the second half's is not read
+                    if constexpr (Stack::kSceneInLds) {
+                        LdsF4 q = st.scene + nodes_at + kLdsNodeWords * cur;
+                        a0 = load_f4(q, 0); a1 = load_f4(q, 1); a2 = load_f4(q, 2); a3 = load_f4(q, 3);
+                        b0 = load_f4(q, 4); b1 = load_f4(q, 5); b2 = load_f4(q, 6);
+                    } else {
+                        GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
+                        a0 = load_f4(q, 0); a1 = load_f4(q, 1); a2 = load_f4(q, 2); a3 = load_f4(q, 3);
+                        b0 = load_f4(q, 4); b1 = load_f4(q, 5); b2 = load_f4(q, 6);
+                    }
                     cnt.nodes++;
                     const uint32_t r0 = __float_as_uint(a3.x), r1 = __float_as_uint(a3.y), r2 = __float_as_uint(a3.z), r3 = __float_as_uint(a3.w);
                     if constexpr (FAST) {
@@ -153,6 +162,14 @@ struct Flow {
             // (the leaves under one two-level record), up to kLeafRun tests in one trip: its own order of tests and
             // pops is unchanged, and it does not wait for the vote between them.  On binary records one test per trip.
             if (is_tri) {
+                auto exact_tri_test = [&](uint32_t slot, float &t, float &bv, float &bw, uint32_t &prim) -> bool {
+                    if constexpr (Stack::kSceneInLds) {
+                        LdsF4 q = st.scene + tris_at + 3u * slot;
+                        return tri_test_words(load_f4(q, 0), load_f4(q, 1), load_f4(q, 2), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim);
+                    } else {
+                        return tri_test(tris + slot, f.o, f.d, kRayTMin, tmax, t, bv, bw, prim);
+                    }
+                };
                 for (int run = 0; run < (WIDE ? kLeafRun : 1); run++) {
                     float t, bv, bw;
                     uint32_t prim;
@@ -174,7 +191,7 @@ struct Flow {
                                 }
                             }
                         }
-                    } else if (tri_test(tris + (cur & ~kLeafBit), f.o, f.d, kRayTMin, tmax, t, bv, bw, prim)) {
+                    } else if (exact_tri_test(cur & ~kLeafBit, t, bv, bw, prim)) {
                         found = true;
                         if (any) {
                             ended = true;
@@ -201,6 +218,8 @@ struct Flow {
                 const MeshDev &m = sc.meshes[in.mesh];
                 nodes = WIDE ? m.wide : m.nodes;
                 tris = m.tris;
+                nodes_at = m.lds_nodes;
+                tris_at = m.lds_tris;
                 AccelRoot r = m.root;
                 if constexpr (FAST) inst_pos = in.tlas_position;
                 V3 ow, dw;
@@ -220,7 +239,7 @@ struct Flow {
         if (need_pop) {
             cur = kNoNode;
             for (;;) {
-                if (in_blas && sp == sp_base) { in_blas = false; world(f.o, f.d); f.r = world_r; f.fast = world_fast; nodes = WIDE ? sc.top_wide : sc.top_nodes; }
+                if (in_blas && sp == sp_base) { in_blas = false; world(f.o, f.d); f.r = world_r; f.fast = world_fast; nodes = WIDE ? sc.top_wide : sc.top_nodes; nodes_at = sc.lds_top; }
                 if (sp == 0) break;
                 uint2 e = pop();
                 if (within_reach<FAST>(__uint_as_float(e.y), tmax, any)) { cur = e.x; break; }

@@ -180,12 +180,27 @@ void PathTracer::BuildAccel() {
     uint32_t num_instances = (uint32_t)instance_mesh_.size();
     if (num_instances == 0) return;
 
+    // A scene whose traversal records are a few KB gets them once more in one piece, for the kernel that keeps them in
+    // LDS: the top level's node records, then per mesh its node records and its triangle records (16-byte words).
+    const uint32_t top_record_count = num_instances > 1 ? num_instances - 1 : 0;
+    uint32_t lds_words = top_record_count * cpt::kLdsNodeWords;
+    std::vector<uint32_t> lds_nodes_at(meshes_.size()), lds_tris_at(meshes_.size());
+    for (size_t i = 0; i < meshes_.size(); i++) {
+        const uint32_t n = meshes_[i]->num_triangles;
+        lds_nodes_at[i] = lds_words;
+        if (lds_words <= cpt::kLdsSceneBytes / 16) lds_words += (n > 1 ? n - 1 : 0) * cpt::kLdsNodeWords;
+        lds_tris_at[i] = lds_words;
+        if (lds_words <= cpt::kLdsSceneBytes / 16) lds_words += 3 * n;
+    }
+    const bool lds_copy = wide && lds_words <= cpt::kLdsSceneBytes / 16;
+
     // mesh descriptor table; each root record is copied in from where its build left it
     std::vector<cpt::MeshDev> mesh_table(meshes_.size());
     for (size_t i = 0; i < meshes_.size(); i++) {
         MeshBuffers &mb = *meshes_[i];
         cpt::MeshDev &d = mesh_table[i];
         memset(&d, 0, sizeof(d));
+        if (lds_copy) { d.lds_nodes = lds_nodes_at[i]; d.lds_tris = lds_tris_at[i]; }
         d.nodes = wide ? nullptr : mb.packed_nodes.TypedGpuData<cpt::PackedNode>();
         d.tris = mb.tris.TypedGpuData<cpt::TriRecord>();
         d.indices = mb.indices.TypedGpuData<uint32_t>();
@@ -250,6 +265,24 @@ void PathTracer::BuildAccel() {
     binary_records_ = !wide;
     scene_dev_.top_root = top_root_.TypedGpuData<cpt::AccelRoot>();
     scene_dev_.meshes = mesh_table_.TypedGpuData<cpt::MeshDev>();
+
+    scene_dev_.lds_scene = nullptr;
+    scene_dev_.lds_scene_words = 0;
+    scene_dev_.lds_top = 0;
+    lds_scene_.Release();
+    if (lds_copy && lds_words != 0) {
+        lds_scene_.Allocate(16 * (size_t)lds_words);
+        float *blob = lds_scene_.TypedGpuData<float>();
+        rc_check(cpt::launch_lds_scene_nodes(blob, top_wide_.TypedGpuData<cpt::PackedNode>(), top_record_count, stream_), "records for LDS, top level");
+        for (size_t i = 0; i < meshes_.size(); i++) {
+            MeshBuffers &mb = *meshes_[i];
+            const uint32_t n = mb.num_triangles;
+            rc_check(cpt::launch_lds_scene_nodes(blob + 4 * (size_t)lds_nodes_at[i], mb.wide_nodes.TypedGpuData<cpt::PackedNode>(), n > 1 ? n - 1 : 0, stream_), "records for LDS");
+            CPT_HIP(hipMemcpyAsync(blob + 4 * (size_t)lds_tris_at[i], mb.tris.GpuData(), sizeof(cpt::TriRecord) * (size_t)n, hipMemcpyDeviceToDevice, stream_));
+        }
+        scene_dev_.lds_scene = blob;
+        scene_dev_.lds_scene_words = lds_words;
+    }
 }
 
 // The binary node records, for the ordered batch queries: scenes built with two-level records get them the first
@@ -528,18 +561,23 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
     }
     const int variant = integrator == 4 ? 1 : (integrator == 5 ? 2 : 0);
     const int fast = (scene_dev_.fast_traversal != 0 ? 1 : 0) | (scene_dev_.wide_nodes != 0 ? 2 : 0);      // traversal of the kernel build
-    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_traversal_ != fast) {
+    // the copy of the records that the small-scene kernel keeps in LDS goes with the launch only when it is wanted
+    cpt::SceneDev scene = scene_dev_;
+    if (!scene_in_lds_) scene.lds_scene = nullptr;
+    const bool in_lds = variant == 2 && scene.lds_scene != nullptr && !wf_dense_ && fast == 2;
+    if (!queue_.Size() || resident_dense_ != wf_dense_ || resident_variant_ != variant || resident_traversal_ != fast || resident_scene_in_lds_ != in_lds) {
         queue_.Allocate(cpt::kRegenQueueWords * sizeof(uint32_t));
         queue_.Zero(stream_);
         queue_parity_ = 0;
         int device = 0;
         CPT_HIP(hipGetDevice(&device));
-        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, (fast & 1) != 0, (fast & 2) != 0);
+        resident_blocks_ = cpt::render_regen_resident_blocks(device, wf_dense_, variant, (fast & 1) != 0, (fast & 2) != 0, in_lds);
+        resident_scene_in_lds_ = in_lds;
         resident_dense_ = wf_dense_;
         resident_variant_ = variant;
         resident_traversal_ = fast;
     }
-    rc_check(cpt::launch_render_regen(scene_dev_, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, variant, stream_), "render");
+    rc_check(cpt::launch_render_regen(scene, p, queue_.TypedGpuData<uint32_t>(), queue_parity_, (uint32_t)resident_blocks_, wf_dense_, variant, stream_), "render");
     queue_parity_ ^= 1u;
 }
 

@@ -71,6 +71,10 @@ public:
     // (camera rays), so the default (0) is one ray per lane for the whole launch.  Same results either way.
     void FirstHit(const float *d_rays, uint64_t num_rays, uint32_t *d_instance, uint32_t *d_primitive, float *d_t, float *d_uv);
     void SetQueryKernel(int mode) { query_stream_ = mode != 0; }
+    // Whether the kernel for small scenes reads node and triangle records from a copy in LDS (default) or from memory
+    // like every other kernel: same results.  Scenes whose records exceed cpt::kLdsSceneBytes have no such copy.
+    void SetSceneInLds(bool on) { scene_in_lds_ = on; }
+    bool SceneInLds() const { return scene_in_lds_ && lds_scene_.Size() != 0; }
     static constexpr uint64_t kStreamQueryRays = 1u << 16;
     // Renders sample indices [spp_begin, spp_begin + count) (1-based) into `output` (device,
     // W*H float4; the Film when null).  sum_mode adds radiance instead of keeping a running mean.
@@ -138,6 +142,8 @@ private:
     size_t scene_triangles_ = 0;
     uint32_t queue_parity_ = 0;
     int resident_blocks_ = 0;
+    bool resident_scene_in_lds_ = false;     // resident_blocks_ was looked up for the kernel that keeps the records in LDS
+    bool scene_in_lds_ = true;
     cpt::HipBuffer queue_;
     cpt::HipBuffer query_queue_;           // segment cursors of the persistent query kernel
     uint32_t query_parity_ = 0;
@@ -169,6 +175,7 @@ private:
     std::vector<uint32_t> instance_mesh_;            // instance -> mesh table index
     cpt::HipBuffer leaf_scratch_;
     cpt::HipBuffer top_nodes_, top_bboxes_, top_keys_, top_packed_, top_root_, top_wide_;
+    cpt::HipBuffer lds_scene_;       // node and triangle records of a small scene in one piece (SceneDev::lds_scene), or empty
     int node_records_ = 1;
     bool binary_records_ = false;              // the binary node records exist (always when node_records_ is 0)
     void EnsureBinaryRecords();

@@ -341,15 +341,20 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
 // finished takes shadow rays from that list (any lane's), so they fill the slots that would idle and the
 // separate shadow trace disappears.  The owner adds its light contribution when the next shading step
 // finds its ray marked as having reached the light: same order of additions per path as before.
-template <bool DENSE> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 7 : 11; };
+// SCENE_IN_LDS: the node and triangle records of a scene of a few KB (SceneDev::lds_scene) are copied into LDS by every
+// workgroup, and the traversal reads them there: no record visit goes through the vector memory pipeline, whose address
+// unit the 36-triangle Cornell box keeps busy 63 % of the time with everything in the L1.  The stack gives up three LDS
+// entries per lane for the room.
+template <bool DENSE, bool SCENE_IN_LDS = false> struct PoolShape { static constexpr int kWaves = DENSE ? 5 : 4, kLdsEntries = DENSE ? 7 : SCENE_IN_LDS ? 8 : 11; };
 #ifndef POOL_MASK
 #define POOL_MASK 7u
 #endif
 constexpr uint32_t kPoolPeriodMask = POOL_MASK;         // lanes are re-assigned every eighth trip
 
-template <bool MAPS, bool DENSE, bool FAST, bool WIDE>
+template <bool MAPS, bool DENSE, bool FAST, bool WIDE, bool SCENE_IN_LDS = false>
 __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_render_pool(SceneDev sc, RenderParams p, uint32_t *queue, uint32_t parity) {
-    __shared__ uint2 s_stack[PoolShape<DENSE>::kLdsEntries * kTraceBlock];
+    __shared__ uint2 s_stack[PoolShape<DENSE, SCENE_IN_LDS>::kLdsEntries * kTraceBlock];
+    __shared__ RawF4 s_scene[SCENE_IN_LDS ? kLdsSceneBytes / 16 : 1];
     __shared__ unsigned long long s_cnt[5];
     // the shadow ray of each lane's path, four 16-byte fields next to each other (64 bytes per lane): (origin, reach),
     // (direction, fast-division flag), (1 / direction, -), (light contribution, reached the light).  Field-major storage
@@ -359,7 +364,13 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     auto pool = [&](uint32_t field, uint32_t slot) -> float4 & { return s_pool[4 * slot + field]; };
     __shared__ uint8_t s_order[kTraceBlock];         // per wave: the lanes that have a shadow ray to be walked, in lane order
     uint2 spill_entries[kSpillEntries];
-    TraceStackT<PoolShape<DENSE>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST, WIDE> st(s_stack, spill_entries, sc.counters);
+    TraceStackT<PoolShape<DENSE, SCENE_IN_LDS>::kLdsEntries, DENSE ? kLeafWeightLargeScene : 1, FAST, WIDE, SCENE_IN_LDS> st(s_stack, spill_entries, sc.counters);
+    if constexpr (SCENE_IN_LDS) {
+        const RawF4 *src = reinterpret_cast<const RawF4 *>(sc.lds_scene);
+        for (uint32_t w = threadIdx.x; w < sc.lds_scene_words; w += kTraceBlock) s_scene[w] = src[w];
+        st.scene = (LdsF4)s_scene;
+        __syncthreads();
+    }
     LaneCounters cnt;
 #ifdef CPT_STEP_STATS
     StepStats stats;
@@ -766,10 +777,11 @@ int selftest_division(uint64_t pairs, uint32_t seed, unsigned long long *d_misma
 template <class F> auto pick(bool v, F &&f) { return v ? f(std::true_type{}) : f(std::false_type{}); }
 
 using RegenKernel = void (*)(SceneDev, RenderParams, uint32_t *, uint32_t);
-RegenKernel regen_kernel(int variant, bool maps, bool dense, bool fast, bool wide) {
+RegenKernel regen_kernel(int variant, bool maps, bool dense, bool fast, bool wide, bool scene_in_lds) {
     return pick(maps, [&](auto M) {
         return pick(dense, [&](auto D) -> RegenKernel {
             constexpr bool m = decltype(M)::value, d = decltype(D)::value;
+            if (variant == 2 && scene_in_lds && !dense && !fast && wide) return k_render_pool<m, false, false, true, true>;
             if (variant == 2) return fast ? (wide ? k_render_pool<m, d, true, true> : k_render_pool<m, d, true, false>) : wide ? k_render_pool<m, d, false, true> : k_render_pool<m, d, false, false>;
             if (variant == 1) return fast ? (wide ? k_render_flow<m, true, true> : k_render_flow<m, true, false>) : wide ? k_render_flow<m, false, true> : k_render_flow<m, false, false>;
             return wide ? k_render_regen<m, d, true> : k_render_regen<m, d, false>;
@@ -795,15 +807,15 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     if ((unsigned long long)tiles * p.spp_count * kSegmentSlots > 0xffffffffull) return (int)hipErrorInvalidValue;
     unsigned long long want = ((unsigned long long)tiles * p.spp_count + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;
-    RegenKernel kernel = regen_kernel(variant, sc.textures != nullptr, dense, sc.fast_traversal != 0, sc.wide_nodes != 0);
+    RegenKernel kernel = regen_kernel(variant, sc.textures != nullptr, dense, sc.fast_traversal != 0, sc.wide_nodes != 0, sc.lds_scene != nullptr);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kTraceBlock), 0, stream, sc, p, queue, parity);
     return (int)hipGetLastError();
 }
 
-int render_regen_resident_blocks(int device, bool dense, int variant, bool fast, bool wide) {
+int render_regen_resident_blocks(int device, bool dense, int variant, bool fast, bool wide, bool scene_in_lds) {
     int per_cu = 0, other = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)regen_kernel(variant, true, dense, fast, wide), kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, (const void *)regen_kernel(variant, false, dense, fast, wide), kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)regen_kernel(variant, true, dense, fast, wide, scene_in_lds), kTraceBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&other, (const void *)regen_kernel(variant, false, dense, fast, wide, scene_in_lds), kTraceBlock, 0) != hipSuccess || other < 1) other = 1;
     if (other < per_cu) per_cu = other;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return per_cu * cus;
@@ -861,6 +873,19 @@ int launch_occlude(const SceneDev &sc, const float *rays, uint64_t n, uint8_t *o
         return fast ? k_occlude<l, true, false> : wide ? k_occlude<l, false, true> : k_occlude<l, false, false>;
     });
     hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(kTraceBlock), 0, stream, sc, rays, count, out);
+    return (int)hipGetLastError();
+}
+
+// Node records as the LDS copy of a small scene holds them: the kLdsNodeWords 16-byte words of each two-level record that a visit reads
+__global__ void __launch_bounds__(kTraceBlock) k_lds_scene_nodes(RawF4 *__restrict__ dst, const RawF4 *__restrict__ wide, uint32_t words) {
+    const uint32_t w = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (w < words) dst[w] = wide[8u * (w / kLdsNodeWords) + w % kLdsNodeWords];
+}
+int launch_lds_scene_nodes(float *dst, const PackedNode *wide, uint32_t records, hipStream_t stream) {
+    const uint32_t words = records * kLdsNodeWords;
+    if (words == 0) return 0;
+    hipLaunchKernelGGL(k_lds_scene_nodes, dim3((words + kTraceBlock - 1) / kTraceBlock), dim3(kTraceBlock), 0, stream, reinterpret_cast<RawF4 *>(dst),
+                       reinterpret_cast<const RawF4 *>(wide), words);
     return (int)hipGetLastError();
 }
 

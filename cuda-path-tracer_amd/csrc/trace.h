@@ -43,7 +43,9 @@ typedef uint32_t RawU2 __attribute__((ext_vector_type(2)));
 typedef const RawF4 __attribute__((address_space(1))) *GlobalF4;
 typedef RawU2 __attribute__((address_space(3))) *LdsStack;
 typedef RawU2 __attribute__((address_space(5))) *PrivateStack;
+typedef const RawF4 __attribute__((address_space(3))) *LdsF4;
 __device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ inline float4 load_f4(LdsF4 p, int i) { RawF4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 // LDS_ENTRIES is a kernel's trade between LDS per workgroup (occupancy) and how deep a tree goes
 // before entries land in private memory.  The two arrays live in the kernel (a __shared__ array of
@@ -51,13 +53,17 @@ __device__ inline float4 load_f4(GlobalF4 p, int i) { RawF4 v = p[i]; return mak
 // LEAF_WEIGHT rides along because it is, like the stack's shape, a choice each kernel build makes for the
 // scenes it is meant for (see Traversal::vote_step).
 // FAST selects the ordered traversal (see Traversal) and rides along for the same reason; so does WIDE, which selects
-// the two-level node records (exact traversal only).
-template <int LDS_ENTRIES, int LEAF_WEIGHT = 1, bool FAST = false, bool WIDE = false>
+// the two-level node records (exact traversal only), and SCENE_IN_LDS: the kernel holds the scene's node and triangle records
+// in LDS (SceneDev::lds_scene, copied in by every workgroup) and `scene` points at them (Flow::step reads them there).
+template <int LDS_ENTRIES, int LEAF_WEIGHT = 1, bool FAST = false, bool WIDE = false, bool SCENE_IN_LDS = false>
 struct TraceStackT {
     static constexpr int kLdsEntries = LDS_ENTRIES;
     static constexpr int kLeafWeight = LEAF_WEIGHT;
     static constexpr bool kFast = FAST;
     static constexpr bool kWide = WIDE;
+    static constexpr bool kSceneInLds = SCENE_IN_LDS;
+    static_assert(!SCENE_IN_LDS || (WIDE && !FAST), "the resident copy holds two-level records");
+    LdsF4 scene = nullptr;
     LdsStack lds;
     PrivateStack spill;
     Counters *counters;       // where an entry that does not fit is reported (may be null)
@@ -216,10 +222,8 @@ template <bool FAST> __device__ inline bool within_reach(float t0, float tmax, b
     else return t0 < tmax;
 }
 
-// trimesh.cuh:14-43 on a pre-gathered record
-__device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim) {
-    GlobalF4 q = (GlobalF4)rec;
-    float4 a = load_f4(q, 0), b = load_f4(q, 1), c = load_f4(q, 2);
+// trimesh.cuh:14-43 on a pre-gathered record: its three 16-byte words a, b, c
+__device__ inline bool tri_test_words(float4 a, float4 b, float4 c, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim) {
     V3 p0 = v3(a.x, a.y, a.z), e1 = v3(b.x, b.y, b.z), e2 = v3(c.x, c.y, c.z);
     V3 qv = cross(d, e2);
     float det = dot(e1, qv);
@@ -241,6 +245,11 @@ __device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, fl
         }
     }
     return false;
+}
+__device__ inline bool tri_test(const TriRecord *rec, V3 o, V3 d, float tmin, float tmax, float &t, float &bv, float &bw, uint32_t &prim) {
+    GlobalF4 q = (GlobalF4)rec;
+    const float4 a = load_f4(q, 0), b = load_f4(q, 1), c = load_f4(q, 2);
+    return tri_test_words(a, b, c, o, d, tmin, tmax, t, bv, bw, prim);
 }
 
 // The same test for the ordered traversal: a hit at exactly the current reach is reported too (`tie`), the caller

@@ -249,6 +249,11 @@ int cpt_tracer_occlude(cpt_tracer *t, const float *d_rays, uint64_t num_rays, ui
  * next ray of the batch as soon as theirs is finished -- a quarter to a third faster for rays that diverge (secondary rays),
  * slower for coherent ones (camera rays).  Same results. */
 int cpt_tracer_set_query_kernel(cpt_tracer *t, int mode);
+/* The bounce loop for small scenes (cpt_tracer_set_integrator 5, and 3 below 65,536 triangles) reads node and triangle records
+ * from a copy that every workgroup keeps in LDS when the scene's records are 6 KB or less (no counterpart in the reference):
+ * on != 0 (default) uses that copy, 0 reads memory like every other kernel.  Same film bit for bit.  Returns 1 when the
+ * built scene has such a copy and it is in use, 0 otherwise, negative on error. */
+int cpt_tracer_set_scene_in_lds(cpt_tracer *t, int on);
 /* camera rays of sample index spp for a width*height image, in pixel-index order */
 int cpt_tracer_camera_rays(cpt_tracer *t, uint32_t width, uint32_t height, uint32_t spp, float *d_rays);
 

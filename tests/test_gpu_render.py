@@ -492,6 +492,50 @@ def test_two_level_records_give_the_same_image(cpt):
         assert (work[key][2] == work[(0, 4)][2]) if key[0] == 0 else (work[key][2] < 0.62 * work[(0, 4)][2]), key
 
 
+def test_records_kept_in_lds_give_the_same_image(cpt):
+    """The small-scene bounce loop with the node and triangle records read from its LDS copy and from memory: the same
+    film bit for bit and the same work, one sample per launch and several; the reference's glass-box scene.  A scene whose records exceed the copy's 6 KB has none and says so."""
+    d = os.path.join(SCENES, "cornell-box-glass")
+    sc = cpt.Scene().load_obj(os.path.join(d, "cornell-box.obj"), 2).load_json(os.path.join(d, "cornell-box.json"))
+    W, H = 256, 256
+    films, work = {}, {}
+    for in_lds in (True, False):
+        for per_launch in (1, 8):
+            tr = cpt.Tracer(sc, W, H, max_depth=8)
+            tr.set_integrator(5)
+            tr.build_buffers()
+            assert tr.set_scene_in_lds(in_lds) == in_lds
+            tr.set_samples_per_launch(per_launch)
+            tr.update(16)
+            films[(in_lds, per_launch)] = tr.film()
+            c = tr.counters()
+            work[(in_lds, per_launch)] = (c["rays"], c["tri_tests"], c["node_visits"], c["shades"])
+            assert tr.stack_overflows() == 0
+    ref = films[(False, 1)]
+    assert ref[..., :3].mean() > 1e-3
+    for key, film in films.items():
+        assert np.array_equal(film, ref), key
+        assert work[key] == work[(False, 1)], key
+    # the automatic choice takes the same kernel for this scene
+    tr = cpt.Tracer(sc, W, H, max_depth=8)
+    tr.build_buffers()
+    tr.set_samples_per_launch(8)
+    tr.update(16)
+    assert np.array_equal(tr.film(), ref)
+    # too large for the copy: the switch reports that there is none, and the render is the memory path's
+    objs, cam = synthetic_scene("heightfield", 3000)
+    big = cpt.Scene()
+    for o in objs:
+        big.add_object(o["name"], o["positions"], o["normals"], o["texcoords"], o["indices"], o["material"])
+    big.set_camera(cam["pos"], cam["look_at"], cam["up"], cam["fov"], 64, 64)
+    tr = cpt.Tracer(big, 64, 64, max_depth=4)
+    tr.set_integrator(5)
+    tr.build_buffers()
+    assert tr.set_scene_in_lds(True) is False
+    tr.update(2)
+    assert tr.film()[..., :3].mean() > 1e-4
+
+
 def test_render_entry_point_refuses_a_scene_without_lights(cpt):
     """PathTracer::Update returns early for a scene without an emissive object (/root/reference/src/pathtracer/pathtracer.cpp:27-29);
     the kernel-level entry, which has no film of its own to leave untouched, reports the state instead of launching a kernel
