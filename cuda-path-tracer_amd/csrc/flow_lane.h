@@ -108,8 +108,8 @@ struct Flow {
                         float t[4];
                         uint32_t r[4] = {r0, r1, r2, r3};
                         const bool h0 = slab_fast(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, kRayTMin, t[0]) && within_reach<true>(t[0], tmax, any);
-                        const bool h1 = r1 != kNoNode && slab_fast(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, kRayTMin, t[1]) && within_reach<true>(t[1], tmax, any);
-                        const bool h2 = slab_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, kRayTMin, t[2]) && within_reach<true>(t[2], tmax, any);
+                        const bool h1 = slab_fast(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, kRayTMin, t[1]) && within_reach<true>(t[1], tmax, any);
+                        const bool h2 = r2 != kNoNode && slab_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, kRayTMin, t[2]) && within_reach<true>(t[2], tmax, any);
                         const bool h3 = r3 != kNoNode && slab_fast(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, kRayTMin, t[3]) && within_reach<true>(t[3], tmax, any);
                         if (!h0) { t[0] = inf; r[0] = kNoNode; }
                         if (!h1) { t[1] = inf; r[1] = kNoNode; }
@@ -123,8 +123,8 @@ struct Flow {
                     } else {
                     float t0, t1, t2, t3;
                     const bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, kRayTMin, t0) && t0 < tmax;
-                    const bool h1 = r1 != kNoNode && slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, kRayTMin, t1) && t1 < tmax;
-                    const bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, kRayTMin, t2) && t2 < tmax;
+                    const bool h1 = slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, kRayTMin, t1) && t1 < tmax;       // a record has at least two slots
+                    const bool h2 = r2 != kNoNode && slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, kRayTMin, t2) && t2 < tmax;
                     const bool h3 = r3 != kNoNode && slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, kRayTMin, t3) && t3 < tmax;
                     if (h3 && (h0 || h1 || h2)) push(r3, t3);
                     if (h2 && (h0 || h1)) push(r2, t2);

@@ -770,6 +770,73 @@ __device__ inline bool six_in_fast_range(const float b[6]) {
            coord_in_fast_range(b[5]);
 }
 
+// ---- the four slots of a node's two-level record -------------------------------------------------------------
+// A record holds a cut through the subtree below its node: it starts as (right child, left child) and, twice, the
+// internal member with the largest box surface is replaced by its two children, right one first -- so the members
+// stay in the order the reference's traversal reaches them (right child first, accel.cuh:84-91), and the boxes a ray
+// is most likely to enter are the ones that are opened.  Two levels down on both sides is the cut this gives on a
+// balanced tree; where one child is small or a leaf the other side is opened three levels deep instead.  Measured
+// against the fixed cut of both children's children (a leaf child standing for itself, its half's second slot empty):
+// heightfield 10M 27.1 -> 25.3 records per ray and 591 -> 617 Mpaths/s, soup 1M 103.4 -> 101.8 and 222 -> 226; the
+// Cornell box, whose trees are a dozen triangles, loses 1.2 % (1760 -> 1740).  Opening the node's other child first
+// whenever it is internal and choosing by surface only then: 26.9 records per ray and 594 Mpaths/s, so it is the
+// one-sided openings that pay.  Any cut is valid: a member is walked iff its own box is hit within
+// the reach, which implies that the boxes of the ancestors the cut skipped are (see Traversal::vote_step).
+// Tree: internal(id), children(id, left, right), slot(id, box) -> reference.  Writes the record's seven words that
+// are read and the second half's own reference word (device_types.h: PackedNode halves).
+__device__ inline float box_surface(const float b[6]) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+template <class Tree>
+__device__ inline void store_cut_record(float4 *o, const Tree &tree, uint32_t left, uint32_t right) {
+    constexpr uint32_t kEmpty = 0xffffffffu;
+    uint32_t cut[4] = {right, left, kEmpty, kEmpty};
+    float surface[4] = {-1.0f, -1.0f, -1.0f, -1.0f};       // of internal members; leaves and empty places never win
+    float box[6];
+    auto surface_of = [&](uint32_t id) -> float {
+        if (!tree.internal(id)) return -1.0f;
+        tree.slot(id, box);
+        return box_surface(box);
+    };
+    surface[0] = surface_of(right);
+    surface[1] = surface_of(left);
+#pragma unroll
+    for (int step = 0; step < 2; step++) {
+        int best = -1;
+        float most = -1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (surface[i] > most) { best = i; most = surface[i]; }      // equal surfaces: the earlier member
+        if (best < 0) break;
+        uint32_t opened = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i == best) opened = cut[i];
+        uint32_t l, r;
+        tree.children(opened, l, r);
+        const float sr = surface_of(r), sl = surface_of(l);
+#pragma unroll
+        for (int i = 3; i > 0; i--) {
+            if (i > best + 1) { cut[i] = cut[i - 1]; surface[i] = surface[i - 1]; }
+            else if (i == best + 1) { cut[i] = l; surface[i] = sl; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (i == best) { cut[i] = r; surface[i] = sr; }
+    }
+    const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float a[6], b[6];
+    uint32_t ref[4];
+    // second half first: its references are repeated in the first half's last word
+    if (cut[2] != kEmpty) ref[2] = tree.slot(cut[2], a); else { ref[2] = kNoChild; for (int i = 0; i < 6; i++) a[i] = none[i]; }
+    if (cut[3] != kEmpty) ref[3] = tree.slot(cut[3], b); else { ref[3] = kNoChild; for (int i = 0; i < 6; i++) b[i] = none[i]; }
+    store_half(o + 4, a, ref[2], b, ref[3]);
+    ref[0] = tree.slot(cut[0], a);
+    ref[1] = tree.slot(cut[1], b);
+    o[0] = make_float4(a[0], a[1], a[2], a[3]);
+    o[1] = make_float4(a[4], a[5], b[0], b[1]);
+    o[2] = make_float4(b[2], b[3], b[4], b[5]);
+    o[3] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+}
+
 template <bool PARENTS, int BLOCK, bool RECORDS>
 __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__ keys, const Bbox *__restrict__ leaf_src, Bbox *bboxes, AccelNode *nodes,
                                                     uint32_t *parents, uint32_t *slots, Carrier *carriers, uint32_t *carrier_counts, uint32_t carrier_limit, Bbox merged, uint32_t n,
@@ -979,23 +1046,19 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
                 const uint32_t leaf = e - BLOCK;
                 return kLeafBit | (rec.top_level ? b.z : b0 + leaf);
             };
-            const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float lbox[6], rbox[6];
             const uint32_t lref = slot_of(own.z, lbox), rref = slot_of(own.w, rbox);
             if (!six_in_fast_range(lbox) || !six_in_fast_range(rbox)) atomicOr(&rec.root->flags, 1u);
             if (rec.binary) store_half(reinterpret_cast<float4 *>(rec.binary + (b0 + t)), lbox, lref, rbox, rref);
             if (rec.wide) {
-                float4 *o = reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)(b0 + t));
-                auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) -> uint2 {
-                    if (child >= (uint32_t)BLOCK) { store_half(h, cbox, cref, none, kNoChild); return make_uint2(cref, kNoChild); }
-                    const uint4 c = s_node[child][1];
-                    float first[6], second[6];
-                    const uint32_t second_ref = slot_of(c.z, second), first_ref = slot_of(c.w, first);      // right child first
-                    store_half(h, first, first_ref, second, second_ref);
-                    return make_uint2(first_ref, second_ref);
-                };
-                half(own.w, rbox, rref, o);
-                reinterpret_cast<uint2 *>(o + 3)[1] = half(own.z, lbox, lref, o + 4);      // the second half's references once more, next to the first half's
+                struct {
+                    decltype(slot_of) &slot_fn;
+                    uint4 (*entries)[2];
+                    __device__ bool internal(uint32_t e) const { return e < (uint32_t)BLOCK; }
+                    __device__ void children(uint32_t e, uint32_t &l, uint32_t &r) const { const uint4 c = entries[e][1]; l = c.z; r = c.w; }
+                    __device__ uint32_t slot(uint32_t e, float box[6]) const { return slot_fn(e, box); }
+                } tree{slot_of, s_node};
+                store_cut_record(reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)(b0 + t)), tree, own.z, own.w);
             }
         }
     }
@@ -1005,11 +1068,7 @@ __global__ void __launch_bounds__(BLOCK) k_build_up(const uint64_t *__restrict__
 }
 
 // Records of one internal node from the finished arrays in memory.  Binary: both children's boxes and references.
-// Two-level: two halves in the same layout, the first for the right child, the second for the left child; a half holds
-// the child itself when the child is a leaf (second slot empty: reference kNoChild), otherwise the child's two
-// children, right one first, so that the four slots are in the order the reference's traversal (right child first,
-// accel.cuh:84-91) reaches them.  The first half's two spare words repeat the second half's references: the traversal
-// reads all four from one 16-byte word and never loads the record's last one (seven loads per visit instead of eight).
+// Two-level: see store_cut_record.
 __device__ inline void box6(const Bbox &b, float out[6]) {
     out[0] = b.pmin.x; out[1] = b.pmin.y; out[2] = b.pmin.z; out[3] = b.pmax.x; out[4] = b.pmax.y; out[5] = b.pmax.z;
 }
@@ -1022,20 +1081,13 @@ __device__ inline void pack_from_memory(uint32_t i, const RecordOutputs &rec, co
     const uint32_t lref = child_ref(nd.lc_or_id, nodes, n, rec.top_level), rref = child_ref(nd.rc, nodes, n, rec.top_level);
     if (rec.binary) store_half(reinterpret_cast<float4 *>(rec.binary + i), lbox, lref, rbox, rref);
     if (!rec.wide) return;
-    const float none[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    auto half = [&](uint32_t child, const float cbox[6], uint32_t cref, float4 *h) -> uint2 {
-        if (child >= n - 1) { store_half(h, cbox, cref, none, kNoChild); return make_uint2(cref, kNoChild); }
-        const AccelNode c = nodes[child];
-        float first[6], second[6];
-        box6(bboxes[c.rc], first);
-        box6(bboxes[c.lc_or_id], second);
-        const uint32_t first_ref = child_ref(c.rc, nodes, n, rec.top_level), second_ref = child_ref(c.lc_or_id, nodes, n, rec.top_level);
-        store_half(h, first, first_ref, second, second_ref);
-        return make_uint2(first_ref, second_ref);
-    };
-    float4 *o = reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)i);
-    half(nd.rc, rbox, rref, o);
-    reinterpret_cast<uint2 *>(o + 3)[1] = half(nd.lc_or_id, lbox, lref, o + 4);
+    struct {
+        const AccelNode *nodes; const Bbox *bboxes; uint32_t n; int top_level;
+        __device__ bool internal(uint32_t id) const { return id < n - 1; }
+        __device__ void children(uint32_t id, uint32_t &l, uint32_t &r) const { const AccelNode c = nodes[id]; l = c.lc_or_id; r = c.rc; }
+        __device__ uint32_t slot(uint32_t id, float box[6]) const { box6(bboxes[id], box); return child_ref(id, nodes, n, top_level); }
+    } tree{nodes, bboxes, n, rec.top_level};
+    store_cut_record(reinterpret_cast<float4 *>(rec.wide + 2 * (size_t)i), tree, nd.lc_or_id, nd.rc);
 }
 
 // The root record of a BVH (when rec.root is given), and the records of the internal nodes the hierarchy pass did not

@@ -393,10 +393,11 @@ struct Traversal {
         bool need_pop = false;
         if (cn >= Stack::kLeafWeight * ct && cn >= Stack::kLeafWeight * ci) {
             if constexpr (WIDE) {
-                // Two levels per record, slots in the order the reference reaches them (right child first).  A slot
-                // is walked iff its own box is hit within the reach: its parent's box contains it, and every operation
-                // of the slab test is monotonic in the box coordinates, so the parent's test (which the reference
-                // makes first) cannot fail where the slot's succeeds, nor can the parent's entry distance be larger.
+                // Up to four nodes from two or three levels below per record, slots in the order the reference reaches
+                // them (right child first).  A slot is walked iff its own box is hit within the reach: the boxes of
+                // the ancestors the record skipped contain it, and every operation of the slab test is monotonic in
+                // the box coordinates, so an ancestor's test (which the reference makes first) cannot fail where the
+                // slot's succeeds, nor can the ancestor's entry distance be larger.
                 if (is_node) {
                     GlobalF4 q = (GlobalF4)(nodes + 2 * (size_t)cur);
                     const float4 a0 = load_f4(q, 0), a1 = load_f4(q, 1), a2 = load_f4(q, 2), a3 = load_f4(q, 3);
@@ -408,8 +409,8 @@ struct Traversal {
                         float t[4];
                         uint32_t r[4] = {r0, r1, r2, r3};
                         const bool h0 = slab_fast(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, tmin, t[0]) && within_reach<true>(t[0], tmax, ANY);
-                        const bool h1 = r1 != kNoNode && slab_fast(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t[1]) && within_reach<true>(t[1], tmax, ANY);
-                        const bool h2 = slab_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t[2]) && within_reach<true>(t[2], tmax, ANY);
+                        const bool h1 = slab_fast(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t[1]) && within_reach<true>(t[1], tmax, ANY);
+                        const bool h2 = r2 != kNoNode && slab_fast(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t[2]) && within_reach<true>(t[2], tmax, ANY);
                         const bool h3 = r3 != kNoNode && slab_fast(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, tmin, t[3]) && within_reach<true>(t[3], tmax, ANY);
                         if (!h0) { t[0] = inf; r[0] = kNoNode; }
                         if (!h1) { t[1] = inf; r[1] = kNoNode; }
@@ -423,8 +424,8 @@ struct Traversal {
                     } else {
                     float t0, t1, t2, t3;
                     const bool h0 = slab(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, f, tmin, t0) && t0 < tmax;
-                    const bool h1 = r1 != kNoNode && slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t1) && t1 < tmax;
-                    const bool h2 = slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t2) && t2 < tmax;
+                    const bool h1 = slab(a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, f, tmin, t1) && t1 < tmax;       // a record has at least two slots
+                    const bool h2 = r2 != kNoNode && slab(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, f, tmin, t2) && t2 < tmax;
                     const bool h3 = r3 != kNoNode && slab(b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, f, tmin, t3) && t3 < tmax;
                     if (h3 && (h0 || h1 || h2)) push(r3, t3);
                     if (h2 && (h0 || h1)) push(r2, t2);

@@ -93,9 +93,11 @@ int cpt_builder_build(cpt_builder *b, void *d_nodes, void *d_bboxes, const void 
 /* cpt_builder_build and, in the same kernels, the traversal records of the tree (no counterpart in the reference, whose
  * traversal reads AccelNode and Bbox, accel.cuh:68-90): num_primitives - 1 binary records of 64 bytes (left child's box
  * min.xyz max.xyz, right child's, left reference, right reference, 8 spare bytes) and / or as many two-level records of
- * 128 bytes (two halves in that layout: the right child's children, right one first, then the left child's; a child
- * that is a leaf fills the first slot of its half and leaves 0xffffffff as the second reference; the first half's spare
- * bytes repeat the second half's two references, so that one 16-byte word holds all four) -- either pointer may
+ * 128 bytes (two halves in that layout, four slots: a cut through the subtree below the node -- its two children, of which
+ * twice the internal one with the largest box surface, fp32 dx*dy + dy*dz + dz*dx, the earlier one on equality, is replaced
+ * by its own two children -- in the order the reference's traversal reaches them, right child first at every level; unused
+ * slots come last with reference 0xffffffff and a zero box; the first half's spare bytes repeat the second half's two
+ * references, so that one 16-byte word holds all four) -- either pointer may
  * be null, not both -- and a root record of 40 bytes (box min.xyz max.xyz, reference, primitive count, flags, spare).
  * A reference with bit 31 set is a leaf: its sorted position, or with top_level != 0 the primitive id.  Only enqueues
  * work. */

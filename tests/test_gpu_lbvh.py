@@ -202,8 +202,10 @@ def test_reusable_builder_is_deterministic(cpt):
 
 def records_from_arrays(nodes, boxes, n, top_level):
     """The traversal records of a finished tree, restated with numpy from the reference-format arrays: binary records
-    (children's boxes and references), two-level records (the grandchildren in the reference's visit order, a leaf child
-    standing for itself) and the root record."""
+    (children's boxes and references), two-level records and the root record.  A two-level record holds a cut through the
+    subtree below its node: (right child, left child) to begin with, then twice the internal member with the largest
+    box surface (fp32, dx*dy + dy*dz + dz*dx; the earlier member on equality) is replaced by its children, right one
+    first; members in that order in slots 0..3, unused slots with reference 0xffffffff and a zero box."""
     LEAF, NONE = np.uint32(0x80000000), np.uint32(0xFFFFFFFF)
     ids = np.arange(2 * n - 1, dtype=np.uint32)
     leaf_ref = LEAF | (nodes[:, 0] if top_level else ids - np.uint32(n - 1))
@@ -217,16 +219,33 @@ def records_from_arrays(nodes, boxes, n, top_level):
         return out
 
     binary = half(box6[lc], ref[lc], box6[rc], ref[rc])
-    wide = np.zeros((n - 1, 32), np.uint32)
-    for side, child in ((0, rc), (1, lc)):
-        leaf = child >= n - 1
-        inner = np.where(leaf, 0, child)
-        first, second = nodes[inner, 1], nodes[inner, 0]                    # the child's right child, then its left child
-        a = np.where(leaf[:, None], box6[child], box6[first])
-        ra = np.where(leaf, ref[child], ref[first])
-        b = np.where(leaf[:, None], 0, box6[second])
-        rb = np.where(leaf, NONE, ref[second])
-        wide[:, 16 * side:16 * side + 16] = half(a, ra.astype(np.uint32), b.astype(np.uint32), rb.astype(np.uint32))
+    d = boxes[:, 4:7] - boxes[:, 0:3]                                       # float32 throughout, as on the device
+    surface = (d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2]) + d[:, 2] * d[:, 0]
+    all_lc, all_rc = nodes[:, 0].astype(np.int64), nodes[:, 1].astype(np.int64)
+    internal = np.arange(2 * n - 1) < n - 1
+    m = n - 1
+    cut = np.full((m, 4), -1, np.int64)
+    cut[:, 0], cut[:, 1] = rc, lc
+    rows = np.arange(m)
+    for _ in range(2):
+        member = np.maximum(cut, 0)
+        s_of = np.where((cut >= 0) & internal[member], surface[member], np.float32(-1.0))
+        best = s_of.argmax(axis=1)                                          # first of equal maxima
+        can = s_of[rows, best] > -1.0
+        opened = cut[rows, best]
+        new = cut.copy()
+        for col in range(4):
+            new[:, col] = np.where(col < best, cut[:, col],
+                          np.where(col == best, all_rc[np.maximum(opened, 0)],
+                          np.where(col == best + 1, all_lc[np.maximum(opened, 0)], cut[:, max(col - 1, 0)])))
+        cut = np.where(can[:, None], new, cut)
+    wide = np.zeros((m, 32), np.uint32)
+    for slot in range(4):
+        used = cut[:, slot] >= 0
+        member = np.maximum(cut[:, slot], 0)
+        base = 16 * (slot // 2) + 6 * (slot % 2)
+        wide[:, base:base + 6] = np.where(used[:, None], box6[member], 0)
+        wide[:, 16 * (slot // 2) + 12 + slot % 2] = np.where(used, ref[member], NONE)
     wide[:, 14:16] = wide[:, 28:30]                                         # the second half's references once more: one 16-byte word has all four
     root = np.zeros(10, np.uint32)
     root[0:6] = box6[0]
