@@ -477,7 +477,7 @@ void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
     while (count != 0) {
         uint32_t batch = 1;
         if (folds && count > 1) {
-            const unsigned long long tiles = (unsigned long long)((p.width + 7) / 8) * ((p.height + 7) / 8);
+            const unsigned long long tiles = cpt::render_tile_count(p.width, p.height);
             const unsigned long long fits = tiles ? 0xffffffffull / (tiles * cpt::kSegmentSlots) : 1;       // slot numbers are 32 bits
             batch = (uint32_t)std::min<unsigned long long>({(unsigned long long)count, (unsigned long long)samples_per_launch_, fits ? fits : 1});
         }

@@ -24,6 +24,8 @@ constexpr uint32_t kRegenQueueWords = 2 * kCursorSetWords;
 // mean into a film whose alpha is 0 or 1 everywhere) or p.order must point to
 // width * height zeroed words.  The film ends up bit for bit as after one launch per sample.
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream);
+// tiles (of 64 path slots) one sample of a width x height film takes in those kernels: whole blocks of 16 x 16 tiles
+uint32_t render_tile_count(uint32_t width, uint32_t height);
 int render_regen_resident_blocks(int device, bool dense, int variant, bool fast, bool wide, bool scene_in_lds);
 // `records` two-level node records in the form the LDS copy of a small scene holds them (SceneDev::lds_scene): kLdsNodeWords 16-byte words each
 int launch_lds_scene_nodes(float *dst, const PackedNode *wide, uint32_t records, hipStream_t stream);

@@ -15,6 +15,23 @@ namespace cpt {
 
 namespace {
 
+// Tiles of 8 x 8 pixels, one wave each, in the order the persistent kernels hand them out: blocks of 16 x 16 tiles, row by
+// row inside a block and block after block (the tile count is rounded up to whole blocks; tiles outside the film hand out
+// no pixels), so that the few hundred tiles the waves of one XCD hold at a time form a patch of the image and not one row of
+// it, and their rays meet in the caches more often.  Against plain rows of tiles, Mpaths/s: heightfield 10M 617 -> 623, soup 1M
+// 225 -> 226, Cornell box 1741 -> 1748; blocks of 4 / 8 / 32 tiles: 617 / 618 / 624 on the heightfield.
+constexpr uint32_t kTileBlock = 16;
+__host__ __device__ inline uint32_t tile_count(uint32_t width, uint32_t height) {
+    const uint32_t tx = (width + 7) / 8, ty = (height + 7) / 8;
+    return ((tx + kTileBlock - 1) / kTileBlock) * ((ty + kTileBlock - 1) / kTileBlock) * kTileBlock * kTileBlock;
+}
+__device__ inline void tile_pixel(uint32_t tile, uint32_t k, uint32_t width, uint32_t &px, uint32_t &py) {
+    const uint32_t blocks_x = ((width + 7) / 8 + kTileBlock - 1) / kTileBlock;
+    const uint32_t block = tile / (kTileBlock * kTileBlock), in = tile % (kTileBlock * kTileBlock);
+    px = ((block % blocks_x) * kTileBlock + in % kTileBlock) * 8 + (k & 7u);
+    py = ((block / blocks_x) * kTileBlock + in / kTileBlock) * 8 + (k >> 3);
+}
+
 // src/kernels/integrator/path.cu:9-83
 template <bool MAPS, class Stack>
 __device__ inline V3 trace_path(const SceneDev &sc, V3 ro, V3 rd, Sampler &sampler, uint32_t max_depth, int channel, Stack &st, LaneCounters &cnt) {
@@ -132,7 +149,7 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    const uint32_t tiles = tile_count(p.width, p.height);
     uint32_t *cursors = queue + parity * kCursorSetWords;
     zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
 
@@ -143,13 +160,14 @@ __global__ void __launch_bounds__(kTraceBlock, RegenShape<DENSE>::kWaves) k_rend
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!l.alive);
         while (idle != 0ull && !f.exhausted) {
-            if (f.remaining() == 0 && !f.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane)) break;
+            if (f.remaining() == 0 && !f.advance(nullptr, cursors, tiles, blockIdx.x, lane)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
             const uint32_t take = min((uint32_t)__popcll(idle), f.remaining());
             const uint32_t slot = f.entry(rank);
             if (!l.alive && rank < take) {
                 const uint32_t tile = slot >> 6, k = slot & 63u;
-                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                uint32_t px, py;
+                tile_pixel(tile, k, p.width, px, py);
                 if (px < p.width && py < p.height) {
                     pixel_ray(sc.camera, p.width, p.height, px, py, p.spp, l.sampler, l.pixel_index, l.ro, l.rd);
                     l.alive = true; l.primary = true; l.last_specular = false;
@@ -233,7 +251,7 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    const uint32_t tiles = tile_count(p.width, p.height);
     uint32_t *cursors = queue + parity * kCursorSetWords;
     zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
 
@@ -259,13 +277,14 @@ __global__ void __launch_bounds__(kTraceBlock, kFlowWaves) k_render_flow(SceneDe
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
         while (idle != 0ull && !fetch.exhausted) {
-            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane, p.spp_count)) break;
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles, blockIdx.x, lane, p.spp_count)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
             const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
             const uint32_t slot = fetch.entry(rank);
             if (!s.l.alive && rank < take) {
-                const uint32_t pass = (slot >> 6) / (tiles_x * tiles_y), tile = (slot >> 6) % (tiles_x * tiles_y), k = slot & 63u;
-                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                const uint32_t pass = (slot >> 6) / tiles, tile = (slot >> 6) % tiles, k = slot & 63u;
+                uint32_t px, py;
+                tile_pixel(tile, k, p.width, px, py);
                 if (px < p.width && py < p.height) {
                     PathLane &l = s.l;
                     l.pass = pass; l.film_pending = false;
@@ -380,7 +399,7 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
     uint32_t paths = 0;
     const uint32_t lane = threadIdx.x & 63, wave_base = threadIdx.x & ~63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t tiles_x = (p.width + 7) / 8, tiles_y = (p.height + 7) / 8;
+    const uint32_t tiles = tile_count(p.width, p.height);
     uint32_t *cursors = queue + parity * kCursorSetWords;
     zero_cursors(queue + (parity ^ 1u) * kCursorSetWords);      // the next launch's cursors
 
@@ -396,13 +415,14 @@ __global__ void __launch_bounds__(kTraceBlock, PoolShape<DENSE>::kWaves) k_rende
         // ---- hand new pixels to idle lanes
         unsigned long long idle = __ballot(!s.l.alive);
         while (idle != 0ull && !fetch.exhausted) {
-            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles_x * tiles_y, blockIdx.x, lane, p.spp_count)) break;
+            if (fetch.remaining() == 0 && !fetch.advance(nullptr, cursors, tiles, blockIdx.x, lane, p.spp_count)) break;
             const uint32_t rank = __popcll(idle & lt_mask);
             const uint32_t take = min((uint32_t)__popcll(idle), fetch.remaining());
             const uint32_t slot = fetch.entry(rank);
             if (!s.l.alive && rank < take) {
-                const uint32_t pass = (slot >> 6) / (tiles_x * tiles_y), tile = (slot >> 6) % (tiles_x * tiles_y), k = slot & 63u;
-                const uint32_t px = (tile % tiles_x) * 8 + (k & 7u), py = (tile / tiles_x) * 8 + (k >> 3);
+                const uint32_t pass = (slot >> 6) / tiles, tile = (slot >> 6) % tiles, k = slot & 63u;
+                uint32_t px, py;
+                tile_pixel(tile, k, p.width, px, py);
                 if (px < p.width && py < p.height) {
                     PathLane &l = s.l;
                     l.pass = pass; l.film_pending = false;
@@ -799,8 +819,10 @@ int launch_render(const SceneDev &sc, const RenderParams &p, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+uint32_t render_tile_count(uint32_t width, uint32_t height) { return tile_count(width, height); }
+
 int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *queue, uint32_t parity, uint32_t max_blocks, bool dense, int variant, hipStream_t stream) {
-    uint32_t tiles = ((p.width + 7) / 8) * ((p.height + 7) / 8);
+    uint32_t tiles = tile_count(p.width, p.height);
     if (tiles == 0) return 0;
     if (p.spp_count == 0 || (p.spp_count > 1 && (variant == 0 || (!p.order && !p.turn_in_alpha)))) return (int)hipErrorInvalidValue;
     if (p.turn_in_alpha && (p.sum_mode || p.spp_count > (1u << 23))) return (int)hipErrorInvalidValue;
