@@ -615,7 +615,12 @@ __device__ inline void store_box_sc1(Bbox *p, f32x4 lo, f32x4 hi) {
 // device-scope loads of the sibling box.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSlotValid = 0x80000000u;
-constexpr int kUpBlock = 512;              // leaves per workgroup of the bottom-up pass (256 / 512 / 1024 measured: 0.161 / 0.163 / 0.189 ms for the 1M build)
+// Leaves per workgroup of the bottom-up pass.  512 for inputs up to kSmallSort keys (256 / 512 / 1024: 0.157 / 0.154 / 0.156 ms
+// for the 1M build), 1024 above: with 35 KB of LDS per 512 leaves two workgroups of 1024 share a CU, half as many nodes are
+// left for the pass through memory, and the 10M build takes 0.803 instead of 0.834 ms (256: 0.903).  The scratch is sized
+// for the smaller groups.
+constexpr int kUpBlock = 512;
+constexpr int kUpBlockLarge = 1024;
 
 __device__ inline int wave_incl_min(int v) {
     int lane = threadIdx.x & 63;
@@ -1247,22 +1252,26 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
     }
     mark(2);
     if (n > 1) {
-        const uint32_t groups = cdiv(n, kUpBlock);
+        const bool large = n > kSmallSort;
+        const uint32_t up_block = large ? kUpBlockLarge : kUpBlock;
+        const uint32_t groups = cdiv(n, up_block);
         const uint32_t carrier_limit = ws->carrier_limit < kCarriersPerGroup ? ws->carrier_limit : kCarriersPerGroup;
         if (!slots_cleared) HIP_OK(hipMemsetAsync(slots, 0, 4 * (size_t)(n - 1), stream));      // one exchange word per split
         const RecordOutputs rec = records ? *records : RecordOutputs{};
         if (records) HIP_OK(hipMemsetAsync(rec.root, 0, sizeof(AccelRoot), stream));
         auto first_pass = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(groups), dim3(kUpBlock), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers, carrier_counts,
+            hipLaunchKernelGGL(kernel, dim3(groups), dim3(up_block), 0, stream, src, leaf_src, bboxes, nodes, parents_out, slots, carriers, carrier_counts,
                                carrier_limit, merged, n, rec, local_mask);
         };
         if (parents_out) {
-            if (records) first_pass(k_build_up<true, kUpBlock, true>); else first_pass(k_build_up<true, kUpBlock, false>);
+            if (large) { if (records) first_pass(k_build_up<true, kUpBlockLarge, true>); else first_pass(k_build_up<true, kUpBlockLarge, false>); }
+            else if (records) first_pass(k_build_up<true, kUpBlock, true>); else first_pass(k_build_up<true, kUpBlock, false>);
             mark(3);
             hipLaunchKernelGGL(k_climb<true>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, parents_out, slots, merged, n);
         } else {
-            if (records) first_pass(k_build_up<false, kUpBlock, true>); else first_pass(k_build_up<false, kUpBlock, false>);
+            if (large) { if (records) first_pass(k_build_up<false, kUpBlockLarge, true>); else first_pass(k_build_up<false, kUpBlockLarge, false>); }
+            else if (records) first_pass(k_build_up<false, kUpBlock, true>); else first_pass(k_build_up<false, kUpBlock, false>);
             mark(3);
             hipLaunchKernelGGL(k_climb<false>, dim3(cdiv(groups, kBlock / kCarriersPerGroup)), dim3(kBlock), 0, stream, carriers, carrier_counts, groups, src,
                                bboxes, nodes, (uint32_t *)nullptr, slots, merged, n);

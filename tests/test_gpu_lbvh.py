@@ -255,7 +255,8 @@ def records_from_arrays(nodes, boxes, n, top_level):
 
 
 @pytest.mark.parametrize("n,kind,limit,top_level", [(1, "soup", 64, 0), (2, "soup", 64, 1), (3, "soup", 64, 0), (513, "soup", 64, 0), (5000, "soup", 64, 1),
-                                                    (100000, "soup", 64, 0), (100000, "soup", 0, 0), (70000, "heightfield", 3, 1), (1_200_000, "heightfield", 64, 0)])
+                                                    (100000, "soup", 64, 0), (100000, "soup", 0, 0), (70000, "heightfield", 3, 1), (1_200_000, "heightfield", 64, 0),
+                                                    (3_300_000, "soup", 64, 0), (3_300_000, "heightfield", 2, 0)])      # above 3M keys: groups of 1024 leaves
 def test_traversal_records_written_by_the_build(cpt, n, kind, limit, top_level):
     """cpt_builder_build_records: the binary and the two-level records that the hierarchy passes write themselves (from
     LDS for nodes finished inside a workgroup, from memory for the others, also when the hand-over list is cut short)
