@@ -256,12 +256,19 @@ def records_from_arrays(nodes, boxes, n, top_level):
 
 @pytest.mark.parametrize("n,kind,limit,top_level", [(1, "soup", 64, 0), (2, "soup", 64, 1), (3, "soup", 64, 0), (513, "soup", 64, 0), (5000, "soup", 64, 1),
                                                     (100000, "soup", 64, 0), (100000, "soup", 0, 0), (70000, "heightfield", 3, 1), (1_200_000, "heightfield", 64, 0),
-                                                    (3_300_000, "soup", 64, 0), (3_300_000, "heightfield", 2, 0)])      # above 3M keys: groups of 1024 leaves
+                                                    (3_300_000, "soup", 64, 0), (3_300_000, "heightfield", 2, 0),      # above 3M keys: groups of 1024 leaves
+                                                    (20000, "stacked", 64, 0), (700, "stacked", 1, 1)])                  # many equal keys: chains instead of balanced subtrees
 def test_traversal_records_written_by_the_build(cpt, n, kind, limit, top_level):
     """cpt_builder_build_records: the binary and the two-level records that the hierarchy passes write themselves (from
     LDS for nodes finished inside a workgroup, from memory for the others, also when the hand-over list is cut short)
     equal a numpy packing of the tree's reference-format arrays, bit for bit; so does the root record."""
-    mesh = random_soup(n, seed=91 + n) if kind == "soup" else heightfield(int((n / 2) ** 0.5), int((n / 2) ** 0.5), 5)
+    if kind == "stacked":
+        # a few hundred distinct triangles, each repeated many times: equal Morton codes, told apart by the index bits
+        # of the key only, so the tree has long runs of nodes whose boxes are equal (equal surfaces: the cut's tie rule)
+        mesh = random_soup(max(n // 64, 4), seed=5 + n)
+        mesh["indices"] = np.tile(mesh["indices"].reshape(-1, 3), (64, 1)).reshape(-1)[: 3 * n]
+    else:
+        mesh = random_soup(n, seed=91 + n) if kind == "soup" else heightfield(int((n / 2) ** 0.5), int((n / 2) ** 0.5), 5)
     boxes, merged = boxes_of_triangles(mesh["positions"], mesh["indices"])
     n = len(boxes)
     d_leaf = cpt.DeviceArray.from_host(boxes)

@@ -157,6 +157,22 @@ def test_synthetic_scenes(cpt, kind, ntris):
     assert np.array_equal(tr.occlude(sh), osc.occlude(sh))
 
 
+def test_coincident_triangles_report_the_reference_winner(cpt):
+    """Every triangle of the mesh sixteen times over: sixteen hits at exactly the same distance on every ray that hits, of
+    which the reference keeps the first its visit order meets (strict less-than, trimesh.cuh:35), and long runs of nodes
+    with equal boxes in the tree.  The records' slots, whichever cut they hold, must keep that order."""
+    objs, cam = synthetic_scene("heightfield", 3000)
+    mesh = objs[0]
+    mesh["indices"] = np.tile(mesh["indices"].reshape(-1, 3), (16, 1)).reshape(-1).copy()
+    osc = OracleScene(objs, cam)
+    for records in (1, 0):
+        sc, tr = gpu_scene(cpt, objs, cam, node_records=records)
+        inst, _ = assert_same_hits(tr, osc, osc.camera_rays(256, 256, 2))
+        assert (inst != 0xFFFFFFFF).mean() > 0.3
+        assert_same_hits(tr, osc, interior_rays(60000, 21, np.array([0, -0.2, 0], np.float32), np.array([1, 1.5, 1], np.float32)))
+        assert tr.stack_overflows() == 0
+
+
 def test_counters_and_edge_cases(cpt):
     objs, cam = cornell(glass=False)
     osc = OracleScene(objs, cam)
