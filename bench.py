@@ -303,7 +303,18 @@ def primary_ray_block(cpt, tracer, W, H, label, valu_peak):
     return out
 
 
+def keep_stdout_for_the_result():
+    """The contract is ONE line on stdout.  Libraries print there too (RCCL writes a version banner when its first
+    communicator comes up), so everything this process and its libraries write to file descriptor 1 goes to stderr from
+    here on, and the result line is written to the descriptor that stdout was."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    result_fd = keep_stdout_for_the_result()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="samples per pixel per GPU in the timed region (default: 512 for the headline workload)")
@@ -637,7 +648,7 @@ def main():
                 others = {}
             result["cpu_baseline"] = head
             result["cpu_baseline_other_configs"] = others
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
 
     if sharded:
         dist.barrier()
