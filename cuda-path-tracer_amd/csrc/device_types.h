@@ -159,6 +159,9 @@ struct RenderParams {
     // Running-mean launches of several samples into a film whose alpha is 0 or 1 everywhere (a film only ever written by
     // running-mean samples and clears) need no `order` array: the count travels in the pixel's alpha, see film_accumulate_in_order.
     int turn_in_alpha = 0;
+    // The same for sums into a film that only clears and sums have written: its alpha IS the number of samples summed so
+    // far, alpha_base of them before this launch, so sample k of the launch writes when it reads alpha == alpha_base + k.
+    uint32_t alpha_base = 0;
 };
 
 }  // namespace cpt

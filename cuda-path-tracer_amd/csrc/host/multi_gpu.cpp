@@ -168,6 +168,7 @@ void ReduceFilmToRoot(PathTracer &tracer, Film &film, ShardComm &comm, int root,
     float *buffer = film.DeviceMap(stream);
     comm.ReduceSum(buffer, (size_t)film.Width() * film.Height() * 4, root, stream);
     if (finish && comm.Rank() == root) FinishSumFilm(buffer, film.Width(), film.Height(), stream);
+    tracer.NoteFilmExposed();        // the root's film now holds other ranks' samples (and means, once finished)
 }
 
 }  // namespace cpt
@@ -285,6 +286,7 @@ void MultiPathTracer::Render(uint32_t total_spp, uint32_t first, void (*progress
         t.SetSamplesPerLaunch(samples_per_launch_);
         t.SetWavefrontTail(wavefront_tail_);
         s.film->Clear(t.Stream());
+        t.NoteFilmCleared();
         const cpt::SampleBlock block = cpt::split_samples(total_spp, (uint32_t)i, world, first);
         const uint32_t step = progress ? 16u : (block.count ? block.count : 1u);
         for (uint32_t at = 0; at < block.count; at += step) {
@@ -323,6 +325,7 @@ void MultiPathTracer::Render(uint32_t total_spp, uint32_t first, void (*progress
         DeviceScope scope(root.device);
         cpt::FinishSumFilm(film_.DeviceMap(root.tracer->Stream()), film_.Width(), film_.Height(), root.tracer->Stream());
     }
+    for (Shard &s : shards_) s.tracer->NoteFilmExposed();       // the films hold other shards' sums now
     Synchronize();
     last_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -98,6 +98,7 @@ bool PathTracer::RefreshEdits(bool restart) {
         ResetAccumelation();
         film_.Clear(stream_);
         film_alpha_unit_ = true;
+        film_sum_count_ = 0;
     }
     return changed;
 }
@@ -430,7 +431,7 @@ void PathTracer::Update() {
     RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
-        if (last_width_ != 0) film_alpha_unit_ = true;       // a resized film starts from zeros
+        if (last_width_ != 0) { film_alpha_unit_ = true; film_sum_count_ = 0; }       // a resized film starts from zeros
         last_width_ = film_.Width();
         last_height_ = film_.Height();
     }
@@ -444,6 +445,7 @@ void PathTracer::Update() {
     p.channel = display_channel_;
     p.sum_mode = 0;
     LaunchSample(p);
+    film_sum_count_ = -1;            // a running mean leaves another alpha
     film_.DeviceUnmap();
 }
 
@@ -454,7 +456,7 @@ void PathTracer::UpdateMany(uint32_t count) {
     RefreshEdits();
     if (film_.Width() != last_width_ || film_.Height() != last_height_) {
         ResetAccumelation();
-        if (last_width_ != 0) film_alpha_unit_ = true;       // a resized film starts from zeros
+        if (last_width_ != 0) { film_alpha_unit_ = true; film_sum_count_ = 0; }       // a resized film starts from zeros
         last_width_ = film_.Width();
         last_height_ = film_.Height();
     }
@@ -482,8 +484,16 @@ void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
             batch = (uint32_t)std::min<unsigned long long>({(unsigned long long)count, (unsigned long long)samples_per_launch_, fits ? fits : 1});
         }
         p.turn_in_alpha = 0;
-        if (batch > 1 && !p.sum_mode && film_alpha_unit_ && p.output == film_.DeviceMap(stream_)) {
+        p.alpha_base = 0;
+        const bool film_memory = p.output == film_.DeviceMap(stream_);
+        const bool own_film = film_memory && p.width == film_.Width() && p.height == film_.Height();
+        if (film_memory && !own_film) { film_alpha_unit_ = false; film_sum_count_ = -1; }       // a window of other extents over the film's memory
+        if (batch > 1 && !p.sum_mode && film_alpha_unit_ && own_film) {
             p.turn_in_alpha = 1;           // the pixel's alpha carries the count during the launch
+            p.order = nullptr;
+        } else if (batch > 1 && p.sum_mode && own_film && film_sum_count_ >= 0 && film_sum_count_ + batch < (1ll << 24)) {
+            p.turn_in_alpha = 1;           // sums: the alpha is the count
+            p.alpha_base = (uint32_t)film_sum_count_;
             p.order = nullptr;
         } else if (batch > 1) {
             const size_t words = (size_t)p.width * p.height;
@@ -495,6 +505,10 @@ void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
         }
         p.spp_count = batch;
         LaunchSample(p);
+        if (own_film) {
+            if (!p.sum_mode) film_sum_count_ = -1;                   // running means leave another alpha
+            else if (film_sum_count_ >= 0) film_sum_count_ += batch;
+        }
         p.spp += batch;
         count -= batch;
     }

@@ -35,8 +35,8 @@ public:
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
     // the film's memory was cleared / may have been written by someone else (its device pointer was handed out)
-    void NoteFilmCleared() { film_alpha_unit_ = true; }
-    void NoteFilmExposed() { film_alpha_unit_ = false; }
+    void NoteFilmCleared() { film_alpha_unit_ = true; film_sum_count_ = 0; }
+    void NoteFilmExposed() { film_alpha_unit_ = false; film_sum_count_ = -1; }
     // 0: the reference's traversal order and arithmetic, results bit for bit the reference's (default); 1: ordered
     // traversal (nearer child first, slab distances by reciprocal multiplication): same hit distances, but among
     // triangles at (nearly) the same distance another one may be reported.  Used by the batch queries and by
@@ -151,6 +151,7 @@ private:
     bool query_stream_ = false;
     cpt::HipBuffer order_;                 // one word per pixel for launches of several samples (RenderParams::order)
     bool restart_pending_ = false;         // an edit was uploaded by RefreshEdits(false); the accumulation has not been restarted yet
+    long long film_sum_count_ = 0;         // the film holds the sums of this many samples and nothing else (its alpha is that count everywhere); -1: not known
     bool film_alpha_unit_ = true;          // every alpha of the film is 0 or 1: nothing but running-mean samples and clears has written it
     uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample (later, with 0.824 at 32: 64 -> 0.817, 128 -> 0.814, 256 -> 0.813, 1024 -> 0.811)
     void LaunchSample(const cpt::RenderParams &p);

@@ -111,6 +111,14 @@ __device__ inline bool film_accumulate_in_order(const RenderParams &p, uint32_t 
                      : "=&v"(prev)
                      : "v"(pixel)
                      : "memory");
+        if (p.sum_mode) {
+            // sums: the alpha of the film is the count of samples it holds (device_types.h: alpha_base)
+            if (prev.w != (float)(p.alpha_base + pass)) return false;
+            if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
+            const FilmF4 sum = FilmF4{prev.x + color.x, prev.y + color.y, prev.z + color.z, prev.w + 1.0f};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(pixel), "v"(sum) : "memory");
+            return true;
+        }
         if (pass != 0u && prev.w != (float)(pass + 1u)) return false;
         if (isnan(color.x) || isnan(color.y) || isnan(color.z) || isinf(color.x) || isinf(color.y) || isinf(color.z)) color = v3(0.0f);
         const float alpha_in = pass == 0u ? prev.w : 1.0f;

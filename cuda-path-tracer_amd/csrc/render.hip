@@ -825,7 +825,7 @@ int launch_render_regen(const SceneDev &sc, const RenderParams &p, uint32_t *que
     uint32_t tiles = tile_count(p.width, p.height);
     if (tiles == 0) return 0;
     if (p.spp_count == 0 || (p.spp_count > 1 && (variant == 0 || (!p.order && !p.turn_in_alpha)))) return (int)hipErrorInvalidValue;
-    if (p.turn_in_alpha && (p.sum_mode || p.spp_count > (1u << 23))) return (int)hipErrorInvalidValue;
+    if (p.turn_in_alpha && (p.spp_count > (1u << 23) || (p.sum_mode && (unsigned long long)p.alpha_base + p.spp_count > (1ull << 24)))) return (int)hipErrorInvalidValue;
     if ((unsigned long long)tiles * p.spp_count * kSegmentSlots > 0xffffffffull) return (int)hipErrorInvalidValue;
     unsigned long long want = ((unsigned long long)tiles * p.spp_count + kTraceBlock / 64 - 1) / (kTraceBlock / 64);
     uint32_t blocks = want < max_blocks ? (uint32_t)want : max_blocks;

@@ -610,11 +610,44 @@ def test_sums_rendered_into_the_films_own_pointer_are_followed_by_correct_means(
     assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
 
 
+def test_sums_into_the_tracers_own_film_over_several_calls(cpt):
+    """Sums rendered into the tracer's own film keep the pixel's sample count in its alpha and take their turn from it
+    (no turn words), over several calls in a row: 5 + 11 + 1 + 9 samples in launches of up to 8 leave what one launch per
+    sample leaves, also at a size where a pixel's samples run on different XCDs, and so do sums that follow a handed-out
+    film pointer or running means (the tracer no longer knows the alpha and goes back to turn words)."""
+    objs, cam = cornell(glass=True)
+    for W, H, mode in ((200, 120, 4), (1024, 1024, 5)):
+        films, later = [], []
+        for per_launch in (1, 8):
+            sc, tr = gpu_scene(cpt, objs, cam, W, H, max_depth=6)
+            tr.set_integrator(mode)
+            tr.set_samples_per_launch(per_launch)
+            at = 1
+            for n in (5, 11, 1, 9):
+                tr.render_samples(at, n, True)
+                at += n
+            tr.synchronize()
+            films.append(tr.film())
+            cpt.lib.cpt_tracer_film_device_ptr(tr.h)          # from here on the film's content is the caller's business
+            tr.render_samples(at, 6, True)
+            tr.synchronize()
+            later.append(tr.film())
+            tr.update(3)                                      # running means over the sums: an alpha of neither kind
+            tr.render_samples(at + 6, 5, True)
+            tr.synchronize()
+            later.append(tr.film())
+        assert np.all(films[0][..., 3] == 26.0) and np.all(later[0][..., 3] == 32.0)
+        assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32)), (W, H)
+        assert np.array_equal(later[0].view(np.uint32), later[2].view(np.uint32)), (W, H)
+        assert np.array_equal(later[1].view(np.uint32), later[3].view(np.uint32)), (W, H)
+
+
 def test_film_ordered_by_fences_leaves_the_same_film(cpt):
     """Launches of several samples order a pixel's samples by hand-placed device-scope accesses (integrate.h:
     film_accumulate_in_order); libcpt_amd_fences.so is the same library with that order kept by acquire / release instead.
-    Sums (turn words) and running means (count in the alpha) at the Cornell configuration's size, 64 samples in launches of
-    32, rendered by both libraries in separate processes: the same film bit for bit."""
+    Sums through a handed-out film pointer (turn words; sums into a film the tracer knows to be cleared keep the count in
+    the alpha like the running means) and running means at the Cornell configuration's size, 64 samples in launches of 32,
+    rendered by both libraries in separate processes: the same film bit for bit."""
     fences = os.path.join(os.path.dirname(cpt.LIB_PATH), "libcpt_amd_fences.so")
     assert os.path.exists(fences), "build it with make -C cuda-path-tracer_amd/csrc"
     program = (
@@ -627,7 +660,11 @@ def test_film_ordered_by_fences_leaves_the_same_film(cpt):
         "tr = cpt.Tracer(sc, 1024, 1024, max_depth=8)\n"
         "tr.set_integrator(5); tr.set_samples_per_launch(32); tr.build_buffers()\n"
         "tr.render_samples(1, 64, True); tr.synchronize()\n"
+        "counted = hashlib.sha256(tr.film().tobytes()).hexdigest()\n"
+        "tr.reset(); ptr = cpt.lib.cpt_tracer_film_device_ptr(tr.h)\n"
+        "tr.render_samples(1, 64, True, ptr, 1024, 1024); tr.synchronize()\n"
         "sums = hashlib.sha256(tr.film().tobytes()).hexdigest()\n"
+        "assert sums == counted\n"
         "tr.reset(); tr.update(64)\n"
         "print(os.path.basename(cpt.LIB_PATH), sums, hashlib.sha256(tr.film().tobytes()).hexdigest(), tr.counters()['paths'])\n"
     ) % (ROOT, ROOT)
@@ -642,4 +679,4 @@ def test_film_ordered_by_fences_leaves_the_same_film(cpt):
         lines.append(r.stdout.strip().splitlines()[-1].split())
     assert lines[0][0] == "libcpt_amd.so" and lines[1][0] == "libcpt_amd_fences.so"
     assert lines[0][1:] == lines[1][1:], lines
-    assert int(lines[0][3]) == 1024 * 1024 * 128
+    assert int(lines[0][3]) == 1024 * 1024 * 192
