@@ -769,7 +769,7 @@ int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s) {
 }
 
 int cpt_valu_issue_rate(int mix, int waves_per_simd, double *ginst_per_s, double *cycles_per_inst, double *shader_mhz) {
-    if (!ginst_per_s || mix < 0 || mix > 1 || waves_per_simd < 1 || waves_per_simd > 8) return Fail(CPT_ERR_INVALID, "cpt_valu_issue_rate: mix 0 or 1, 1 to 8 waves per SIMD");
+    if (!ginst_per_s || mix < 0 || mix > 2 || waves_per_simd < 1 || waves_per_simd > 8) return Fail(CPT_ERR_INVALID, "cpt_valu_issue_rate: mix 0, 1 or 2, 1 to 8 waves per SIMD");
     return Guard([&] {
         int device = 0, cus = 0;
         CPT_HIP(hipGetDevice(&device));

@@ -689,7 +689,8 @@ __global__ void __launch_bounds__(256) k_stream_copy(const RawF4 *__restrict__ s
 // Vector-instruction issue rate of the device, measured: every wave runs `iterations` trips of 64 independent vector
 // instructions on 16 accumulators (no memory access, no dependence shorter than 16 instructions) and notes the shader
 // clock before and after.  MIX 0: v_fma_f32 only.  MIX 1: the kinds a slab test is made of (subtract, multiply,
-// compare + select, max, min).  The host sizes the grid so that a chosen number of waves shares each SIMD; the quotient
+// compare + select, max, min).  MIX 2: v_pk_fma_f32 only (two fp32 operations per lane and instruction, on register
+// pairs).  The host sizes the grid so that a chosen number of waves shares each SIMD; the quotient
 // instructions / time over the whole device is the ceiling a traversal kernel's instruction count is set against.
 template <int MIX>
 __global__ void __launch_bounds__(256) k_valu_rate(uint32_t iterations, float seed, float *sink, unsigned long long *cycles) {
@@ -697,6 +698,11 @@ __global__ void __launch_bounds__(256) k_valu_rate(uint32_t iterations, float se
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = seed + (float)(threadIdx.x + k);
     const float x = 1.0f + seed * 1e-9f, y = seed * 1e-3f;
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    Pair p[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[k] = Pair{a[k], a[k] + 0.25f};
+    const Pair px = Pair{x, x}, py = Pair{y, y};
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (uint32_t i = 0; i < iterations; i++) {
 #pragma unroll
@@ -704,6 +710,9 @@ __global__ void __launch_bounds__(256) k_valu_rate(uint32_t iterations, float se
             if (MIX == 0) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
+            } else if (MIX == 2) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(px), "v"(py));
             } else {
 #pragma unroll
                 for (int k = 0; k < 16; k += 8) {
@@ -721,7 +730,7 @@ __global__ void __launch_bounds__(256) k_valu_rate(uint32_t iterations, float se
     const unsigned long long t1 = __builtin_readcyclecounter();
     float total = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) total += a[k];
+    for (int k = 0; k < 16; k++) total += a[k] + (MIX == 2 ? p[k].x + p[k].y : 0.0f);
     if (total == 123.456f) sink[0] = total;            // keeps the accumulators alive; never true for the seeds used
     if ((threadIdx.x & 63u) == 0u) cycles[(blockIdx.x * 256u + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -775,7 +784,7 @@ int launch_valu_rate(int mix, int waves_per_simd, int compute_units, uint32_t it
     if (waves_per_simd < 1 || waves_per_simd > 8 || compute_units < 1) return (int)hipErrorInvalidValue;
     uint32_t lds = (160u * 1024u / (uint32_t)waves_per_simd) & ~1023u;
     if (lds > 64u * 1024u) lds = 64u * 1024u;
-    void (*kernel)(uint32_t, float, float *, unsigned long long *) = mix == 0 ? k_valu_rate<0> : k_valu_rate<1>;
+    void (*kernel)(uint32_t, float, float *, unsigned long long *) = mix == 0 ? k_valu_rate<0> : mix == 1 ? k_valu_rate<1> : k_valu_rate<2>;
     hipLaunchKernelGGL(kernel, dim3((uint32_t)(compute_units * waves_per_simd)), dim3(256), lds, stream, iterations, 0.5f, sink, cycles);
     return (int)hipGetLastError();
 }

@@ -337,7 +337,8 @@ int cpt_stream_copy_rate(uint64_t bytes, int repeats, double *gb_per_s);
 
 /* Device measurement with no counterpart in the reference: the rate at which the device issues vector instructions.
  * Every SIMD of every CU runs `waves_per_simd` (1 to 8) waves of independent wave64 instructions that touch no memory:
- * mix 0 = v_fma_f32 only, mix 1 = the kinds a box test is made of (subtract, multiply, compare + select, max, min).
+ * mix 0 = v_fma_f32 only, mix 1 = the kinds a box test is made of (subtract, multiply, compare + select, max, min),
+ * mix 2 = v_pk_fma_f32 only (packed: two fp32 operations per lane and instruction).
  * ginst_per_s receives 1e9 wave64 instructions per second over the whole device -- the ceiling the instruction counts of
  * the traversal kernels are set against; cycles_per_inst (optional) the shader-clock cycles one wave spent per instruction
  * (waves_per_simd of them share a SIMD, so the SIMD issues one every cycles_per_inst / waves_per_simd); shader_mhz

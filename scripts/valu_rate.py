@@ -7,7 +7,7 @@ from conftest import load_cpt
 cpt = load_cpt()
 cpt.require_device()
 out = {}
-for mix, name in ((0, "v_fma_f32"), (1, "slab mix (sub, mul, cmp+cndmask, max, min)")):
+for mix, name in ((0, "v_fma_f32"), (1, "slab mix (sub, mul, cmp+cndmask, max, min)"), (2, "v_pk_fma_f32 (two fp32 operations per instruction)")):
     rows = {}
     for w in (1, 2, 3, 4, 5, 6, 8):
         g, c, mhz = C.c_double(0), C.c_double(0), C.c_double(0)
