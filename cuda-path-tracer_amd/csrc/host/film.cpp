@@ -10,6 +10,8 @@ void Film::Init(uint32_t width, uint32_t height) {
     width_ = width;
     height_ = height;
     allocated_ = false;      // device memory is taken on first use, so a Film can exist without a GPU
+    zero_generation_++;
+    mapped_since_zeroed_ = false;
 }
 
 void Film::Resize(uint32_t width, uint32_t height) {
@@ -26,12 +28,15 @@ float *Film::DeviceMap(hipStream_t stream) {
         CPT_HIP(hipStreamSynchronize(stream));
         allocated_ = true;
     }
+    mapped_since_zeroed_ = true;
     return buffer_.TypedGpuData<float>();
 }
 
 void Film::Clear(hipStream_t stream) {
     float *p = DeviceMap(stream);
     CPT_HIP(hipMemsetAsync(p, 0, (size_t)width_ * height_ * 16, stream));
+    zero_generation_++;
+    mapped_since_zeroed_ = false;
 }
 
 void Film::ReadBack(float *dst, hipStream_t stream) {

@@ -20,6 +20,10 @@ public:
     float *DeviceMap(hipStream_t stream = nullptr);
     void DeviceUnmap() {}
     void Clear(hipStream_t stream = nullptr);
+    // Counts the times the buffer was made all zeros (created, resized, cleared), and whether its pointer has been handed
+    // out since the last of them: what a renderer needs to know that the content is still what it left there.
+    uint64_t ZeroGeneration() const { return zero_generation_; }
+    bool MappedSinceZeroed() const { return mapped_since_zeroed_; }
 
     // host copy of the buffer, W*H*4 floats
     void ReadBack(float *dst, hipStream_t stream = nullptr);
@@ -30,6 +34,8 @@ private:
     void Init(uint32_t width, uint32_t height);
     uint32_t width_ = 0, height_ = 0;
     bool allocated_ = false;
+    uint64_t zero_generation_ = 0;
+    bool mapped_since_zeroed_ = false;
     cpt::HipBuffer buffer_;
 };
 

@@ -21,7 +21,19 @@ inline void rc_check(int rc, const char *what) {
 constexpr size_t kLargeSceneTriangles = 65536;
 }  // namespace
 
-PathTracer::PathTracer(Scene &scene, Film &film) : scene_(scene), film_(film) {}
+PathTracer::PathTracer(Scene &scene, Film &film) : scene_(scene), film_(film) {
+    film_zero_generation_ = film_.ZeroGeneration();
+    if (film_.MappedSinceZeroed()) NoteFilmExposed();        // a film that has been in other hands: nothing is known about its alphas
+}
+
+// What the tracer believes about the film's alphas (all 0 or 1; all equal to a count of summed samples) holds for the
+// content it left there.  A Film that was cleared or resized since is all zeros again, whoever did it.
+void PathTracer::SyncFilmState() {
+    if (film_.ZeroGeneration() == film_zero_generation_) return;
+    film_zero_generation_ = film_.ZeroGeneration();
+    film_alpha_unit_ = true;
+    film_sum_count_ = 0;
+}
 
 PathTracer::~PathTracer() {
     workspace_.release();
@@ -444,6 +456,7 @@ void PathTracer::Update() {
     p.max_depth = static_cast<uint32_t>(max_depth_);
     p.channel = display_channel_;
     p.sum_mode = 0;
+    SyncFilmState();
     LaunchSample(p);
     film_sum_count_ = -1;            // a running mean leaves another alpha
     film_.DeviceUnmap();
@@ -474,6 +487,7 @@ void PathTracer::UpdateMany(uint32_t count) {
 }
 
 void PathTracer::LaunchSamples(cpt::RenderParams p, uint32_t count) {
+    SyncFilmState();
     const int integrator = integrator_ == 3 ? (wf_dense_ ? 4 : 5) : integrator_;
     const bool folds = (integrator == 4 || integrator == 5) && samples_per_launch_ > 1;
     while (count != 0) {
@@ -598,6 +612,7 @@ void PathTracer::LaunchSample(const cpt::RenderParams &p) {
 void PathTracer::RenderSamples(uint32_t spp_begin, uint32_t count, bool sum_mode, float *output, uint32_t width, uint32_t height) {
     if (!built_ || !has_camera_ || num_lights_ == 0 || instance_mesh_.empty()) return;
     RefreshEdits();
+    SyncFilmState();
     // the film's alpha becomes a sample count, also when the caller passes the film's own pointer back in
     if (sum_mode && (!output || output == film_.DeviceMap(stream_))) film_alpha_unit_ = false;
     cpt::RenderParams p;

@@ -35,6 +35,7 @@ public:
     // ---- additions for batch use (tests, benchmark, multi-GPU sharding)
     void SetChannel(int channel) { display_channel_ = channel; }
     // the film's memory was cleared / may have been written by someone else (its device pointer was handed out)
+    // (a clear or resize of the Film itself is noticed without being told: SyncFilmState)
     void NoteFilmCleared() { film_alpha_unit_ = true; film_sum_count_ = 0; }
     void NoteFilmExposed() { film_alpha_unit_ = false; film_sum_count_ = -1; }
     // 0: the reference's traversal order and arithmetic, results bit for bit the reference's (default); 1: ordered
@@ -151,10 +152,12 @@ private:
     bool query_stream_ = false;
     cpt::HipBuffer order_;                 // one word per pixel for launches of several samples (RenderParams::order)
     bool restart_pending_ = false;         // an edit was uploaded by RefreshEdits(false); the accumulation has not been restarted yet
+    uint64_t film_zero_generation_ = 0;    // Film::ZeroGeneration() when the two below were last brought up to date
     long long film_sum_count_ = 0;         // the film holds the sums of this many samples and nothing else (its alpha is that count everywhere); -1: not known
     bool film_alpha_unit_ = true;          // every alpha of the film is 0 or 1: nothing but running-mean samples and clears has written it
     uint32_t samples_per_launch_ = 32;        // measured on cornell-box-glass 1024 x 1024: 1 -> 1.30, 8 -> 0.90, 16 -> 0.87, 32 -> 0.85, 64 -> 0.84 ms per sample (later, with 0.824 at 32: 64 -> 0.817, 128 -> 0.814, 256 -> 0.813, 1024 -> 0.811)
     void LaunchSample(const cpt::RenderParams &p);
+    void SyncFilmState();
     void LaunchSamples(cpt::RenderParams p, uint32_t count);     // samples p.spp .. p.spp + count - 1
     void LaunchWavefront(const cpt::RenderParams &p);
     cpt::HipBuffer wf_state_, wf_queues_;
