@@ -215,7 +215,11 @@ uint32_t cpt_tracer_num_lights(const cpt_tracer *t);
  * reference's spp counter, each an independent random stream (seeded by pixel and sample index,
  * src/kernels/integrator/path.cu:92).  sum_mode = 1 accumulates plain sums (alpha counts samples)
  * so that buffers of different devices can be added; sum_mode = 0 keeps the reference's running
- * mean.  d_output (W*H*4 floats) may be NULL to use the tracer's film.  Asynchronous. */
+ * mean.  d_output (W*H*4 floats) may be NULL to use the tracer's film.  Asynchronous.
+ * Launches of several samples keep a pixel's samples in sample order.  Into the tracer's own film, while the tracer
+ * knows what the film holds (from cpt_tracer_reset_accumulation on: nothing but its own sums, or nothing but its own
+ * running means), the pixel's alpha carries the turn; after cpt_tracer_film_device_ptr has handed the memory out, or
+ * into any other buffer, a word per pixel kept by the tracer does.  Same film bit for bit either way. */
 int cpt_tracer_render_samples(cpt_tracer *t, uint32_t spp_begin, uint32_t spp_count, int sum_mode, float *d_output, uint32_t width,
                               uint32_t height);
 /* Replaces: static void kernel::PathTracer::Render(const Params &)   src/kernels/integrator/path.cuh:8-22, path.cu:109-115,
