@@ -324,17 +324,26 @@ __global__ void __launch_bounds__(THREADS) k_hist(const uint64_t *__restrict__ k
     if (threadIdx.x < kBins) tile_hist[(size_t)threadIdx.x * num_tiles + blockIdx.x] = hist[threadIdx.x];   // bin-major
 }
 
-// one workgroup per bin: exclusive scan of that bin's counts over all tiles, total to bin_total
+// one workgroup per bin: exclusive scan of that bin's counts over all tiles, total to bin_total.  A lane takes kScanRun
+// consecutive counts, all loaded before the first is used, so up to 4096 tiles (16.7M keys) are one round of loads and
+// one scan over the workgroup instead of a round per 256 tiles.
+constexpr int kScanRun = 16;
 __global__ void __launch_bounds__(kBlock) k_scan_bins(uint32_t *__restrict__ tile_hist, uint32_t num_tiles, uint32_t *__restrict__ bin_total) {
     __shared__ uint32_t tmp[kWaves + 1];
     uint32_t *row = tile_hist + (size_t)blockIdx.x * num_tiles;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < num_tiles; base += kBlock) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < num_tiles ? row[i] : 0u;
+    for (uint32_t base = 0; base < num_tiles; base += kBlock * kScanRun) {
+        const uint32_t first = base + threadIdx.x * kScanRun;
+        uint32_t v[kScanRun];
+#pragma unroll
+        for (int j = 0; j < kScanRun; j++) v[j] = first + j < num_tiles ? row[first + j] : 0u;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < kScanRun; j++) { const uint32_t x = v[j]; v[j] = sum; sum += x; }
         uint32_t total;
-        uint32_t ex = block_excl_scan(v, tmp, total);
-        if (i < num_tiles) row[i] = carry + ex;
+        const uint32_t ex = carry + block_excl_scan(sum, tmp, total);
+#pragma unroll
+        for (int j = 0; j < kScanRun; j++) if (first + j < num_tiles) row[first + j] = ex + v[j];
         carry += total;
         __syncthreads();
     }
