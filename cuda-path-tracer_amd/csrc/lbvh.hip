@@ -328,7 +328,18 @@ __global__ void __launch_bounds__(THREADS) k_hist(const uint64_t *__restrict__ k
 // consecutive counts, all loaded before the first is used, so up to 4096 tiles (16.7M keys) are one round of loads and
 // one scan over the workgroup instead of a round per 256 tiles.
 constexpr int kScanRun = 16;
-__global__ void __launch_bounds__(kBlock) k_scan_bins(uint32_t *__restrict__ tile_hist, uint32_t num_tiles, uint32_t *__restrict__ bin_total) {
+//
+// The scan keeps one workgroup per CU busy for a few microseconds and nothing else runs beside it, so the large
+// configuration hands it a share of a chore that is pure bandwidth: workgroups past the first kBins zero 4 KB each of
+// `clear` (the hierarchy pass's exchange words, a quarter of them per sort pass) instead of a 40 MB memset between the
+// sort and the hierarchy pass.
+__global__ void __launch_bounds__(kBlock) k_scan_bins(uint32_t *__restrict__ tile_hist, uint32_t num_tiles, uint32_t *__restrict__ bin_total, uint4 *__restrict__ clear,
+                                                      uint32_t clear_count) {
+    if (blockIdx.x >= kBins) {
+        const uint32_t i = (blockIdx.x - kBins) * kBlock + threadIdx.x;
+        if (i < clear_count) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     __shared__ uint32_t tmp[kWaves + 1];
     uint32_t *row = tile_hist + (size_t)blockIdx.x * num_tiles;
     uint32_t carry = 0;
@@ -1244,7 +1255,7 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
         const uint32_t nt = small ? cdiv(n, kBlock * kSmallItems) : (uint32_t)tiles;
         if (small) hipLaunchKernelGGL((k_morton_tile<kSmallItems, true>), dim3(nt), dim3(kBlock), 0, stream, keys_a, leaf_src, merged, n, tile_hist, nt, slots);
         else hipLaunchKernelGGL((k_morton_tile<1, false>), dim3(grid_n), dim3(kBlock), 0, stream, keys_a, leaf_src, merged, n, tile_hist, nt, slots);     // one key per lane
-        slots_cleared = small;
+        slots_cleared = n > 1;       // small: by the key kernel; large: beside the scans of the sort passes below
         mark(1);
         if (n > 1) {
             for (int pass = 0; pass < kPasses; pass++) {
@@ -1252,7 +1263,16 @@ int lbvh_build(AccelNode *nodes, Bbox *bboxes, const Bbox &merged, uint32_t n, h
                 if (pass == 0 && small) {}       // the key kernel counted this pass's digits
                 else if (small) hipLaunchKernelGGL((k_hist<kSmallItems, kBlock>), dim3(nt), dim3(kBlock), 0, stream, src, n, shift, tile_hist, nt);
                 else hipLaunchKernelGGL((k_hist<kItems / kHistWide, kBlock * kHistWide>), dim3(nt), dim3(kBlock * kHistWide), 0, stream, src, n, shift, tile_hist, nt);
-                hipLaunchKernelGGL(k_scan_bins, dim3(kBins), dim3(kBlock), 0, stream, tile_hist, nt, bin_total);
+                // large inputs: the exchange words (4 bytes per split, the allocation rounded up to 256) are zeroed beside the scans, a quarter per pass
+                uint32_t clear_count = 0;
+                uint4 *clear = nullptr;
+                if (!small) {
+                    const uint32_t words16 = (uint32_t)(((size_t)4 * n + 255) / 256 * 16), share = cdiv(words16, (uint32_t)kPasses);
+                    const uint32_t begin = share * (uint32_t)pass;
+                    clear_count = begin < words16 ? (words16 - begin < share ? words16 - begin : share) : 0;
+                    clear = reinterpret_cast<uint4 *>(slots) + begin;
+                }
+                hipLaunchKernelGGL(k_scan_bins, dim3(kBins + cdiv(clear_count, (uint32_t)kBlock)), dim3(kBlock), 0, stream, tile_hist, nt, bin_total, clear, clear_count);
                 if (small) hipLaunchKernelGGL((k_scatter<kSmallItems, false>), dim3(nt), dim3(kBlock), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
                                 else hipLaunchKernelGGL((k_scatter_wide<kTile / (kWideWaves * 64), kWideWaves, true>), dim3(nt), dim3(kWideWaves * 64), 0, stream, src, dst, n, shift, tile_hist, bin_total, nt);
                 uint64_t *t = src; src = dst; dst = t;
