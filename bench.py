@@ -31,7 +31,9 @@ on the launch stream, against the 8 TB/s HBM peak (`frac`); `traffic` = HBM byte
 counter passes kept under profiles/ (`counters_from` names the file, the entry and the samples per launch of the pass),
 with `hbm_frac` from it; `valu_frac` = vector instructions per second (same passes) against the issue rate this run
 measured on the device (cpt_valu_issue_rate), `useful_valu_frac` = that x the fraction of lanes active.  Blocks without
-a counter pass carry frac = null.
+a counter pass carry frac = null.  Megakernel rooflines also carry `address_unit`: the traversal's 16-byte lane accesses
+of a launch (seven per record visit, three per triangle test, from this run's work counters) over the launch's CU cycles
+-- the load on the address unit of the vector memory pipeline, which takes diverged lanes one per cycle.
 
 Prints ONE JSON line on rank 0.  Scene data comes from seeded generators (cuda-path-tracer_amd/scenes.py) and the
 committed scene fixtures; nothing outside this repository is read.  The oracle (oracle/) is used only for the
@@ -56,6 +58,7 @@ import scenes  # noqa: E402
 import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E, vendor peak
+SHADER_CLOCK_HZ = 2.4e9                # MI355X engine clock; the render kernels hold it (GRBM_GUI_ACTIVE / 8 XCDs / duration in the counter passes)
 COUNTER_FILE = os.path.join("profiles", "r03_counters.json")
 KERNEL_OF = {0: "k_render_regen", 1: "k_render", 2: "k_wf_generate + k_wf_trace + k_wf_shade + k_wf_finish", 4: "k_render_flow", 5: "k_render_pool"}
 COUNTER_KERNEL = {0: "k_render_regen", 1: "k_render", 2: "k_wf", 4: "k_render_flow", 5: "k_render_pool"}       # first part of a counter entry's key
@@ -145,6 +148,19 @@ def roofline_block(kernel, algorithmic_bytes, avg_ms, samples, m, valu_peak):
     r["counters_from"] = {"file": COUNTER_FILE, "entry": m["key"], "samples_per_launch_of_the_pass": m.get("samples_per_dispatch"), "command": m.get("note", ""),
                           "scaling": "per-sample counter values x the samples this run's launch held"}
     return r
+
+
+def address_unit_block(c, launches, avg_ms, words_per_node, compute_units, clock_hz):
+    """The traversal's load on the address unit of the vector memory pipeline, from this run's work counters: a record
+    visit is words_per_node 16-byte loads per lane and a triangle test three, and the unit takes lanes whose addresses
+    lie in different lines one per cycle (rays that have diverged; lanes of one line share a cycle).  So the lane
+    accesses of a launch over its CU cycles bound how busy the unit is from below for coherent rays and state it for
+    diverged ones; the counter passes under profiles/ (TA_TA_BUSY over TCP_GATE_EN1) hold the measured figure."""
+    accesses = (words_per_node * c["node_visits"] + 3 * c["tri_tests"]) / max(launches, 1)
+    cycles = compute_units * clock_hz * avg_ms * 1e-3
+    return {"traversal_lane_accesses_per_launch": int(accesses), "cu_cycles_per_launch": int(cycles),
+            "lane_accesses_per_cu_cycle": round(accesses / max(cycles, 1.0), 4), "words_per_record_visit": words_per_node,
+            "compute_units": compute_units, "shader_clock_mhz_assumed": round(clock_hz / 1e6, 1)}
 
 
 def cpu_model():
@@ -363,6 +379,9 @@ def main():
     if sharded:
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world, **({} if rehearse else {"device_id": device}))
 
+    props = torch.cuda.get_device_properties(device)
+    compute_units, clock_hz = int(props.multi_processor_count), SHADER_CLOCK_HZ
+
     cpt = load_cpt()
     cpt.check(cpt.lib.cpt_set_device(local_rank))
     kind, ntris_asked, dW, dH, ddepth, dsteps = WORKLOADS[args.workload]
@@ -548,6 +567,7 @@ def main():
         m = measured_counters(f"{COUNTER_KERNEL[integrator]}/{args.workload}/{args.traversal}") if (W, H) == (dW, dH) and max_depth == ddepth else None
         roof = roofline_block(kernel_name, alg_bytes, avg_ms, samples_in_launch, m, valu_peak)
         roof["launches"] = launches
+        roof["address_unit"] = address_unit_block(counters, launches, avg_ms, 7, compute_units, clock_hz)
         if sharded:
             roof["note_multi_gpu"] = "rank 0's launches; avg_launch_ms includes this rank's share of the reduce"
         result["roofline"] = roof
@@ -584,6 +604,8 @@ def main():
                     tag = ("unbounded/" if depth < 0 else "") + ("fast" if trav else "exact")
                     m = measured_counters(f"{COUNTER_KERNEL[mode]}/heightfield-10m/{tag}")
                     v["roofline"] = roofline_block(kname, bounce_bytes(c_own, W * H * S, node_record_bytes(True)) / launches, ms_dev / launches, S / launches, m, valu_peak)
+                    if mode == 4:
+                        v["roofline"]["address_unit"] = address_unit_block(c_own, launches, ms_dev / launches, 7, compute_units, clock_hz)
                     block[name] = v
             tracer.set_max_depth(max_depth)
             tracer.set_integrator(args.integrator)

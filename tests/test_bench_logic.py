@@ -56,3 +56,11 @@ def test_algorithmic_bytes_follow_the_work_counters(bench):
     c = {"rays": 10, "node_visits": 100, "tri_tests": 20, "paths": 4, "shades": 6}
     assert bench.traversal_bytes(c, 128) == 48 * 10 + 128 * 100 + 48 * 20
     assert bench.bounce_bytes(c, 4, 128) == bench.traversal_bytes(c, 128) + 208 * 6 + 32 * 4
+
+
+def test_address_unit_load_follows_the_work_counters(bench):
+    # two launches that made 1000 record visits of seven loads and 100 triangle tests of three, on 10 CUs at 1 GHz for 1 us each
+    c = {"rays": 50, "node_visits": 1000, "tri_tests": 100, "paths": 4, "shades": 6}
+    a = bench.address_unit_block(c, 2, 1e-3, 7, 10, 1e9)
+    assert a["traversal_lane_accesses_per_launch"] == (7 * 1000 + 3 * 100) // 2
+    assert a["cu_cycles_per_launch"] == 10000 and a["lane_accesses_per_cu_cycle"] == 0.365
