@@ -4,7 +4,8 @@ powf flips one of its decisions, and from there the two are independent samples 
 distance of the films falls like Monte Carlo noise restricted to the parted paths.  Scenes: the Cornell box of
 configuration 1 (512 x 512 in the configuration, 256 x 256 here; blinn-phong, max depth 5), cornell-box-glass of configuration 2
 (max depth 8) and the same with unbounded depth; sums of samples 1 .. N on both sides for N = 16 ... 4096.
-usage: python scripts/render_convergence.py [largest N = 4096] [film side = 256]"""
+and two synthetic scenes (heightfield of 1M triangles, soup of 100k) under the benchmark's camera.
+usage: python scripts/render_convergence.py [largest N = 4096] [film side = 256] [only scenes whose name contains this]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,8 +17,18 @@ cpt = load_cpt()
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 side = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 out = {"film": [side, side], "scenes": {}}
-for name, glass, depth in (("cornell-box, max depth 5", False, 5), ("cornell-box-glass, max depth 8", True, 8), ("cornell-box-glass, unbounded depth", True, -1)):
-    objs, cam = cornell(glass=glass, bsdf_type=2)
+from helpers import synthetic_scene
+BENCH_CAMERA = {"pos": np.array([0.5, 0.3, 0.1], np.float32), "look_at": np.array([0.5, 0.0, 0.45], np.float32), "fov": 40.0}
+cases = [("cornell-box, max depth 5", False, 5), ("cornell-box-glass, max depth 8", True, 8), ("cornell-box-glass, unbounded depth", True, -1),
+         ("heightfield 1M triangles, max depth 5", "heightfield", 5), ("soup 100k triangles, max depth 5", "soup", 5)]
+if len(sys.argv) > 3:
+    cases = [c for c in cases if sys.argv[3] in c[0]]
+for name, glass, depth in cases:
+    if isinstance(glass, str):
+        objs, cam = synthetic_scene(glass, 1_000_000 if glass == "heightfield" else 100_000)
+        cam = dict(cam, **BENCH_CAMERA)
+    else:
+        objs, cam = cornell(glass=glass, bsdf_type=2)
     osc = OracleScene(objs, cam)
     sc = cpt.Scene()
     for o in objs:
